@@ -1,0 +1,165 @@
+/*
+ * merlin_hip.h - C ABI of libmerlin_hip.so, the MI355X (gfx950) kernels behind the Merlin /
+ * MMGPT hot path (MMGPTLlamaForCausalLM.forward + backward).
+ *
+ * The reference (Ahnsun/merlin) has NO native/FFI boundary: its hot path is Python calling
+ * torch / transformers / flash-attn.  This header therefore does not replace
+ * an existing FFI; each entry point names the reference call site whose GPU work it takes
+ * over (file:line under /root/reference).  INTEGRATION.md shows the Python binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers unless stated otherwise.
+ *  - the caller allocates everything (outputs, workspaces); the library never allocates,
+ *    frees or synchronises.  Work is enqueued on `stream` (a hipStream_t passed as void*).
+ *  - every function returns 0 on success, a negative MH_ERR_* on bad arguments, or a positive
+ *    hipError_t from the launch.
+ *  - `dt` is the 16-bit storage/MFMA type of activations and weights: MH_BF16 or MH_F16.
+ *    Accumulation, softmax, norms statistics and losses are always fp32.
+ *  - matrices are row-major with explicit leading dimensions in ELEMENTS.
+ */
+#ifndef MERLIN_HIP_H
+#define MERLIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_BF16 0
+#define MH_F16 1
+#define MH_F32 2
+
+#define MH_OK 0
+#define MH_ERR_ARG (-1)    /* bad shape / alignment / null pointer */
+#define MH_ERR_DTYPE (-2)  /* unsupported dtype */
+#define MH_ERR_ARCH (-3)   /* device is not gfx950 */
+#define MH_ERR_SHAPE (-4)  /* shape not supported by this kernel (e.g. head_dim) */
+
+/* epilogue flags for mh_gemm_nt */
+#define MH_EPI_BIAS 1        /* += bias[n]                                   */
+#define MH_EPI_QUICK_GELU 2  /* x * sigmoid(1.702 x)  (CLIP fc1, modeling_clip quick_gelu) */
+#define MH_EPI_RESIDUAL 4    /* += resid[m, n]                               */
+#define MH_EPI_ACCUM 8       /* C = C_old + result (wgrad accumulation)      */
+#define MH_EPI_OUT_F32 16    /* C is fp32 instead of `dt`                    */
+
+int mh_version(void);
+/* 1 if device `dev` is gfx950, else 0 (host query, no stream). */
+int mh_arch_ok(int dev);
+const char* mh_strerror(int code);
+
+/* ---- deterministic weight generator (merlin_amd/weights.py, bit-identical) ------------- */
+/* out[i] = round_bf16(offset + sigma * irwin_hall(key, start + i)), stored as `dt` (incl. MH_F32). */
+int mh_fill_normal(void* out, int64_t n, uint64_t key, int64_t start, float sigma, float offset, int dt, void* stream);
+
+/* ---- GEMM:  C[M,N] = A[M,K] * B[N,K]^T (+epilogue)  ------------------------------------
+ * Replaces every nn.Linear / conv-as-GEMM on the path: q/k/v/o_proj, gate/up/down_proj,
+ * lm_head (llama_flash_attn_monkey_patch.py:35-49,103; llama_mmgpt.py:87), CLIP q/k/v/out,
+ * fc1/fc2, patch embedding (clip_encoder.py:79) and the projector (mlp_projector.py:22).
+ * A, B are `dt`; K % 64 == 0; lda/ldb % 8 == 0; 16-byte aligned bases.  bf16/f16 MFMA, fp32
+ * accumulate.  bias is `dt`[N]; resid is `dt`[M, ldr]. */
+int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+               const void* bias, const void* resid, int64_t ldr,
+               int M, int N, int K, int dt, int epilogue, void* stream);
+
+/* out[C, R_pad] = in[R, C]^T for 16-bit elements (operand re-layout for dgrad / wgrad GEMMs);
+ * columns [R, R_pad) of out are zero filled so the transposed operand's K is a multiple of 64. */
+int mh_transpose16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int R_pad, void* stream);
+
+/* ---- norms -------------------------------------------------------------------------- */
+/* LlamaRMSNorm (transformers modeling_llama.py LlamaRMSNorm; called 65x per forward). */
+int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_or_null, int rows, int d, float eps, int dt, void* stream);
+/* dx (and fp32 partial dw[nblk, d], nblk = mh_norm_bwd_partials(rows)) */
+int mh_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
+/* nn.LayerNorm (CLIP pre_layrnorm / layer_norm1 / layer_norm2, eps 1e-5). */
+int mh_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps, int dt, void* stream);
+int mh_layernorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, float* db_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
+int mh_norm_bwd_partials(int rows);
+/* out[d] (dt) (+)= sum_r partial[r, d]  (finishes dw/db; also bias grads from mh_colsum) */
+int mh_reduce_partials(const float* partial, int nblk, int d, void* out, int dt, int accumulate, void* stream);
+/* partial[nblk, d] = per-row-block column sums of x[rows, d] (bias gradients). nblk = mh_norm_bwd_partials(rows) */
+int mh_colsum_partial(const void* x, int64_t ldx, float* partial, int rows, int d, int dt, void* stream);
+
+/* ---- elementwise -------------------------------------------------------------------- */
+/* LlamaMLP: out[t, f] = silu(gu[t, f]) * gu[t, ff + f]   (gu = fused gate|up GEMM output) */
+int mh_swiglu_fwd(const void* gu, void* out, int rows, int ff, int dt, void* stream);
+/* dgu[t, :] from dout; overwrites dgu */
+int mh_swiglu_bwd(const void* gu, const void* dout, void* dgu, int rows, int ff, int dt, void* stream);
+int mh_quick_gelu_fwd(const void* x, void* y, int64_t n, int dt, void* stream);
+int mh_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt, void* stream);
+/* y = a + b (n elements, 16-bit) */
+int mh_add(const void* a, const void* b, void* y, int64_t n, int dt, void* stream);
+/* generic dtype conversion src(dt_src) -> dst(dt_dst), n elements */
+int mh_convert(const void* src, int dt_src, void* dst, int dt_dst, int64_t n, void* stream);
+
+/* ---- RoPE (rotate-half, theta) on the fused qkv buffer [T, 3, H, D] in place -------------
+ * llama_flash_attn_monkey_patch.py:56-59 (apply_rotary_pos_emb).  pos = t % S.  inverse=1
+ * applies the transposed rotation (backward). */
+int mh_rope_table(float* cos_sin, int S, int D, float theta, void* stream); /* [S, D/2, 2] */
+int mh_rope_qk(void* qkv, const float* cos_sin, int T, int S, int H, int D, int inverse, int dt, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------- */
+/* vt[b, h, d, perm(s)] = qkv[(b*S + s), which=2, h, d]; S_pad = round_up(S, 64); perm swaps
+ * bits 2 and 3 of s (the MFMA k-slot order the attention kernels use). Tail is zero filled. */
+int mh_attn_prep_v(const void* v, int64_t ldv, void* vt, int B, int S, int H, int D, int dt, void* stream);
+/* Flash attention forward.  q/k are [B*S, H, D] views with row stride ldq/ldk (elements);
+ * vt from mh_attn_prep_v; o is [B*S, H*D] (ldo); lse fp32 [B, H, S_pad].  seqlens int32[B] or null
+ * (= S): keys >= seqlens[b] are excluded and query rows >= seqlens[b] are written as zeros,
+ * i.e. flash_attn_varlen + pad_input semantics (llama_flash_attn_monkey_patch.py:87-102).
+ * causal=1: Llama (D=128), causal=0: CLIP (D=64).  scale = 1/sqrt(D). */
+int mh_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, void* o, int64_t ldo,
+                float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
+/* Backward: delta[b,h,s] = rowsum(dO*O) is computed internally into `delta` (fp32 [B,H,S_pad]).
+ * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
+ * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */
+int64_t mh_attn_bwd_ws_elems(int B, int S, int H, int D);
+int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta,
+                void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* ws,
+                const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
+
+/* ---- CLIP patch embedding ------------------------------------------------------------- */
+/* cols[n*G*G + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad.
+ * pixels fp32 (pix_dt = MH_F32) or 16-bit; cols `dt`.  clip_encoder.py:76-79 -> CLIPVisionEmbeddings. */
+int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img, int ps, int Kpad, int dt, void* stream);
+/* x[n, 0, :] = cls + pos[0];  x[n, 1+p, :] = patch[n*G2 + p, :] + pos[1+p]   (then pre_layrnorm) */
+int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x, int N, int G2, int d, int dt, void* stream);
+/* backward of assemble: dpatch rows copy, dcls/dpos partial sums are taken with mh_colsum */
+
+/* ---- embedding + image-feature splice (base_mmgpt.py:99-160) ------------------------------ */
+/* Builds src[b*S+s] = row index into the image-feature matrix [Nimg*P, d] if position s of
+ * sample b is one of the P rows after an <im_start>, else -1 (use embed_tokens[ids]).
+ * img_offset int32[B+1]: exclusive prefix sum of images per sample.  err int32[4] (device):
+ * err[0] != 0 on <im_start>/<im_end> count mismatch (base_mmgpt.py:116-118), err[1] != 0 when
+ * <im_end> is not at start+P+1 (base_mmgpt.py:125-126); err[2], err[3] = (sample, position). */
+int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src, int32_t* err,
+                    int B, int S, int P, int64_t im_patch, int64_t im_start, int64_t im_end, void* stream);
+int mh_embed_splice_fwd(const int64_t* ids, const int32_t* src, const void* embed, const void* feats,
+                        void* out, int T, int d, int dt, void* stream);
+/* dfeats[src] = dout rows (pure copy; rows never collide); dembed32[ids] += dout (fp32 atomics) */
+int mh_embed_splice_bwd(const int64_t* ids, const int32_t* src, const void* dout, void* dfeats, float* dembed32,
+                        int T, int d, int dt, void* stream);
+
+/* ---- shifted cross-entropy (llama_mmgpt.py:92-100) -------------------------------------- */
+/* logits fp32 [B*S, ldl]; labels int64 [B, S].  Row (b,s) is scored against labels[b, s+1]
+ * (ignored when s == S-1 or label == -100).  Writes row_loss[T] (0 for ignored), lse[T];
+ * out2[0] = sum of losses, out2[1] = number of scored rows (fp32), via a final 1-block reduce. */
+int mh_ce_fwd(const float* logits, int64_t ldl, const int64_t* labels, float* row_loss, float* lse, float* out2,
+              int B, int S, int V, void* stream);
+/* dlogits[t, v] (dt, ld = lddl, zero for v in [V, Vpad)) = gscale/count * (softmax - onehot) */
+int mh_ce_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2,
+              void* dlogits, int64_t lddl, int B, int S, int V, int Vpad, float gscale, int dt, void* stream);
+
+/* ---- optimizer (reference: torch AdamW via HF Trainer, trainer.py:45-74) ------------------- */
+/* p, g are `dt`; m, v fp32.  Decoupled weight decay, bias-corrected; gscale multiplies g (1/world, clip). */
+int mh_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float wd, int step, float gscale, int dt, void* stream);
+/* out[0] += sum(g^2) over n elements (fp32 atomic; zero it first) */
+int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERLIN_HIP_H */

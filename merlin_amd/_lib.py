@@ -1,0 +1,55 @@
+"""ctypes binding of libmerlin_hip.so (include/merlin_hip.h).  Fails loudly when the library is
+missing: there is NO CPU / eager fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmerlin_hip.so")
+HEADER = os.path.join(_HERE, "..", "include", "merlin_hip.h")
+
+MH_BF16, MH_F16, MH_F32 = 0, 1, 2
+EPI_BIAS, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16
+
+_lib = None
+
+
+class MerlinHipError(RuntimeError):
+    pass
+
+
+def declared_symbols() -> list:
+    """Every function name declared in include/merlin_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MerlinHipError(
+                f"{LIB_PATH} not found: build it with `python -m merlin_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950).  merlin_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mh_strerror.restype = C.c_char_p
+        _lib.mh_strerror.argtypes = [C.c_int]
+        _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().mh_strerror(code).decode()
+        raise MerlinHipError(f"{what} failed: {msg} (code {code})")
+
+
+def p(t):
+    """device pointer of a tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+i32, i64, f32, u64 = C.c_int, C.c_int64, C.c_float, C.c_uint64

@@ -1,0 +1,61 @@
+"""Build libmerlin_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m merlin_amd.csrc.build [--force]
+
+One object per .hip file (parallel), linked into merlin_amd/csrc/libmerlin_hip.so (in-tree so
+it travels to the GPU box with the snapshot).  No torch dependency: the ABI is plain C.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attn_fwd.hip", "attn_bwd.hip", "loss_splice.hip"]
+LIB = os.path.join(HERE, "libmerlin_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(c) or c == "hipcc":
+            return c
+
+
+def _newer(src, dst):
+    if not os.path.exists(dst):
+        return True
+    deps = [src, os.path.join(HERE, "mh_common.h"), os.path.join(HERE, "..", "..", "include", "merlin_hip.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(dst) for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
+    if not force and not _newer(os.path.join(HERE, src), obj):
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[merlin_amd] built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,320 @@
+// RMSNorm / LayerNorm forward + backward (gfx950).  HBM-bound row kernels:
+//   one wave (64 lanes) per row, 4 rows per 256-thread block, 16-byte (8 x 16-bit) loads per lane,
+//   fp32 statistics reduced with wave shuffles only (no LDS, no barrier in the forward).
+// Backward: dx per row + per-block fp32 partial sums of dw (and db) kept in registers across the
+// block's rows, written once as partial[nblk, d] and finished by mh_reduce_partials (deterministic,
+// no atomics).
+// Reference arithmetic: transformers LlamaRMSNorm (modeling_llama.py: w * x * rsqrt(mean(x^2)+eps))
+// and nn.LayerNorm (CLIP pre_layrnorm / layer_norm1/2, eps 1e-5).
+#include "mh_common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+constexpr int MAX_PARTIALS = 1024;
+
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                     uint16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                     int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const uint4* xr = (const uint4*)(x + (int64_t)row * d);
+  const uint4* wr = (const uint4*)w;
+  uint4* yr = (uint4*)(y + (int64_t)row * d);
+  const int nch = d >> 3;
+  float ss = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)d + eps);
+  if (rstd_out && lane == 0) rstd_out[row] = r;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8], g[8];
+    unpack8<DT>(xr[c], f);
+    unpack8<DT>(wr[c], g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+    yr[c] = pack8<DT>(f);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                       const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                                                       int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const uint4* xr = (const uint4*)(x + (int64_t)row * d);
+  const uint4* wr = (const uint4*)w;
+  const uint4* br = (const uint4*)b;
+  uint4* yr = (uint4*)(y + (int64_t)row * d);
+  const int nch = d >> 3;
+  float s = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += f[i];
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += (f[i] - mu) * (f[i] - mu);
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)d + eps);
+  for (int c = lane; c < nch; c += 64) {
+    float f[8], g[8], h[8];
+    unpack8<DT>(xr[c], f);
+    unpack8<DT>(wr[c], g);
+    unpack8<DT>(br[c], h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (f[i] - mu) * r * g[i] + h[i];
+    yr[c] = pack8<DT>(f);
+  }
+}
+
+// Backward.  LN = false: RMSNorm, LN = true: LayerNorm.  NCH = chunks (of 8 elements) per lane.
+template <int DT, bool LN, int NCH>
+__global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                  const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+                                                  float* __restrict__ dw_partial, float* __restrict__ db_partial,
+                                                  int rows, int d, float eps, int rows_per_block, int accumulate_dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = d >> 3;
+  const uint4* wr = (const uint4*)w;
+  float dwacc[NCH][8];
+  float dbacc[LN ? NCH : 1][8];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dwacc[j][i] = 0.f;
+      if (LN) dbacc[j][i] = 0.f;
+    }
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(rows, r_begin + rows_per_block);
+  const float invd = 1.0f / (float)d;
+  for (int row = r_begin + wave; row < r_end; row += ROWS_PER_BLOCK) {
+    const uint4* xr = (const uint4*)(x + (int64_t)row * d);
+    const uint4* gr = (const uint4*)(dy + (int64_t)row * d);
+    uint4* dxr = (uint4*)(dx + (int64_t)row * d);
+    float xs[NCH][8], gs[NCH][8];  // x (then xhat) and g = w * dy
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        unpack8<DT>(xr[c], xs[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s1 += LN ? xs[j][i] : xs[j][i] * xs[j][i];
+      }
+    }
+    float mu = 0.f, r;
+    if (LN) {
+      mu = wave_sum(s1) * invd;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss += (xs[j][i] - mu) * (xs[j][i] - mu);
+        }
+      }
+      r = rsqrtf(wave_sum(ss) * invd + eps);
+    } else {
+      r = rsqrtf(wave_sum(s1) * invd + eps);
+    }
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float dyf[8], wf[8];
+        unpack8<DT>(gr[c], dyf);
+        unpack8<DT>(wr[c], wf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (xs[j][i] - mu) * r;  // xhat (RMS: mu = 0)
+          xs[j][i] = xh;
+          gs[j][i] = wf[i] * dyf[i];
+          dwacc[j][i] += dyf[i] * xh;
+          if (LN) dbacc[j][i] += dyf[i];
+          sg += gs[j][i];
+          sgx += gs[j][i] * xh;
+        }
+      }
+    }
+    sgx = wave_sum(sgx) * invd;
+    if (LN) sg = wave_sum(sg) * invd; else sg = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = r * (gs[j][i] - sg - xs[j][i] * sgx);
+        if (accumulate_dx) {
+          float p[8];
+          unpack8<DT>(dxr[c], p);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += p[i];
+        }
+        dxr[c] = pack8<DT>(o);
+      }
+    }
+  }
+  // combine the 4 waves' dw/db accumulators through LDS, write this block's partial row
+  float* red = (float*)smem;  // [4][d]
+  const int npass = LN ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[wave * d + c * 8 + i] = (pass == 0) ? dwacc[j][i] : dbacc[LN ? j : 0][i];
+      }
+    }
+    __syncthreads();
+    float* outp = (pass == 0 ? dw_partial : db_partial) + (int64_t)blockIdx.x * d;
+    for (int e = threadIdx.x; e < d; e += 256) outp[e] = red[e] + red[d + e] + red[2 * d + e] + red[3 * d + e];
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ partial, int nblk, int d,
+                                                         void* __restrict__ out, int out_dt, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= d) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * d + e];
+  if (out_dt == MH_F32) {
+    float* o = (float*)out;
+    o[e] = accumulate ? o[e] + s : s;
+  } else {
+    uint16_t* o = (uint16_t*)out;
+    if (accumulate) s += ld16<DT>(o[e]);
+    o[e] = (uint16_t)st16<DT>(s);
+  }
+}
+
+// per-row-block column sums of x[rows, d] (ld = ldx): partial[blk, d]
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_partial_k(const uint16_t* __restrict__ x, int64_t ldx,
+                                                        float* __restrict__ partial, int rows, int d, int rows_per_block) {
+  const int c = blockIdx.y * 256 + threadIdx.x;  // column
+  if (c >= d) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += ld16<DT>(x[(int64_t)r * ldx + c]);
+  partial[(int64_t)blockIdx.x * d + c] = s;
+}
+
+inline int partials_for(int rows) {
+  int n = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return n < MAX_PARTIALS ? n : MAX_PARTIALS;
+}
+
+template <int DT, bool LN>
+int launch_norm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dwp, float* dbp, int rows, int d,
+                    float eps, int acc, hipStream_t st) {
+  const int nblk = partials_for(rows);
+  const int rpb = (rows + nblk - 1) / nblk;
+  const int nch = d >> 3;
+  const int per_lane = (nch + 63) / 64;
+  const size_t lds = (size_t)4 * d * sizeof(float);
+#define LAUNCH(N)                                                                                                   \
+  hipLaunchKernelGGL((norm_bwd_k<DT, LN, N>), dim3(nblk), dim3(256), lds, st, (const uint16_t*)x, (const uint16_t*)w, \
+                     (const uint16_t*)dy, (uint16_t*)dx, dwp, dbp, rows, d, eps, rpb, acc)
+  if (per_lane <= 1) LAUNCH(1);
+  else if (per_lane <= 2) LAUNCH(2);
+  else if (per_lane <= 4) LAUNCH(4);
+  else if (per_lane <= 8) LAUNCH(8);
+  else return MH_ERR_SHAPE;
+#undef LAUNCH
+  MH_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int mh_norm_bwd_partials(int rows) { return partials_for(rows); }
+
+extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int d, float eps, int dt,
+                              void* stream) {
+  if (!x || !w || !y || rows <= 0 || d <= 0 || (d & 7)) return MH_ERR_ARG;
+  const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(rmsnorm_fwd_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,
+                       (const uint16_t*)w, (uint16_t*)y, rstd, rows, d, eps);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(rmsnorm_fwd_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,
+                       (const uint16_t*)w, (uint16_t*)y, rstd, rows, d, eps);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps,
+                                int dt, void* stream) {
+  if (!x || !w || !b || !y || rows <= 0 || d <= 0 || (d & 7)) return MH_ERR_ARG;
+  const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,
+                       (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, rows, d, eps);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(layernorm_fwd_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,
+                       (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, rows, d, eps);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, int rows,
+                              int d, float eps, int dt, int accumulate_dx, void* stream) {
+  if (!x || !w || !dy || !dx || !dw_partial || rows <= 0 || (d & 7)) return MH_ERR_ARG;
+  if (dt == MH_BF16) return launch_norm_bwd<MH_BF16, false>(x, w, dy, dx, dw_partial, nullptr, rows, d, eps, accumulate_dx, as_stream(stream));
+  if (dt == MH_F16) return launch_norm_bwd<MH_F16, false>(x, w, dy, dx, dw_partial, nullptr, rows, d, eps, accumulate_dx, as_stream(stream));
+  return MH_ERR_DTYPE;
+}
+
+extern "C" int mh_layernorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial,
+                                float* db_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream) {
+  if (!x || !w || !dy || !dx || !dw_partial || !db_partial || rows <= 0 || (d & 7)) return MH_ERR_ARG;
+  if (dt == MH_BF16) return launch_norm_bwd<MH_BF16, true>(x, w, dy, dx, dw_partial, db_partial, rows, d, eps, accumulate_dx, as_stream(stream));
+  if (dt == MH_F16) return launch_norm_bwd<MH_F16, true>(x, w, dy, dx, dw_partial, db_partial, rows, d, eps, accumulate_dx, as_stream(stream));
+  return MH_ERR_DTYPE;
+}
+
+extern "C" int mh_reduce_partials(const float* partial, int nblk, int d, void* out, int dt, int accumulate, void* stream) {
+  if (!partial || !out || nblk <= 0 || d <= 0) return MH_ERR_ARG;
+  const int grid = (d + 255) / 256;
+  if (dt == MH_F16)
+    hipLaunchKernelGGL(reduce_partials_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_partials_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_colsum_partial(const void* x, int64_t ldx, float* partial, int rows, int d, int dt, void* stream) {
+  if (!x || !partial || rows <= 0 || d <= 0) return MH_ERR_ARG;
+  const int nblk = partials_for(rows);
+  const int rpb = (rows + nblk - 1) / nblk;
+  dim3 grid(nblk, (d + 255) / 256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(colsum_partial_k<MH_BF16>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, partial, rows, d, rpb);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(colsum_partial_k<MH_F16>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, partial, rows, d, rpb);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}

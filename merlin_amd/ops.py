@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/merlin_hip.h).
+
+PyTorch is used for device memory and streams only: every function checks layouts, allocates
+outputs with torch, and enqueues ONE library call on torch's current HIP stream.  No torch
+arithmetic happens here, and there is no fallback: without libmerlin_hip.so these raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from ._lib import C, f32, i32, i64, p, u64
+
+EPI_BIAS, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_ACCUM, EPI_OUT_F32 = L.EPI_BIAS, L.EPI_QUICK_GELU, L.EPI_RESIDUAL, L.EPI_ACCUM, L.EPI_OUT_F32
+
+
+def dt_of(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.bfloat16:
+        return L.MH_BF16
+    if d == torch.float16:
+        return L.MH_F16
+    if d == torch.float32:
+        return L.MH_F32
+    raise TypeError(f"unsupported dtype {d}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _rowmajor(t: torch.Tensor):
+    assert t.dim() == 2 and t.stride(1) == 1, f"need row-major 2-D, got {tuple(t.shape)} strides {t.stride()}"
+    return t.stride(0)
+
+
+def arch_ok(dev: int = 0) -> bool:
+    return bool(L.lib().mh_arch_ok(i32(dev)))
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out_f32=False, n=None):
+    """out[M,N] = a[M,K] @ b[N,K]^T (+bias)(quick_gelu)(+resid)(+out).  a, b 16-bit, row-major."""
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    assert b.shape[1] == K and a.dtype == b.dtype
+    lda, ldb = _rowmajor(a), _rowmajor(b)
+    if out is None:
+        assert not accum
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
+    ldc = _rowmajor(out)
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+    if act == "quick_gelu":
+        epi |= EPI_QUICK_GELU
+    elif act is not None:
+        raise ValueError(act)
+    ldr = 0
+    if resid is not None:
+        epi |= EPI_RESIDUAL
+        ldr = _rowmajor(resid)
+    if accum:
+        epi |= EPI_ACCUM
+    if out.dtype == torch.float32:
+        epi |= EPI_OUT_F32
+    else:
+        assert out.dtype == a.dtype
+    L.check(L.lib().mh_gemm_nt(p(a), i64(lda), p(b), i64(ldb), p(out), i64(ldc), p(bias), p(resid), i64(ldr),
+                               i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm_nt")
+    return out
+
+
+def transpose16(x, r_pad=None, out=None):
+    """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
+    R, Cc = x.shape
+    ldi = _rowmajor(x)
+    r_pad = R if r_pad is None else r_pad
+    if out is None:
+        out = torch.empty(Cc, r_pad, dtype=x.dtype, device=x.device)
+    L.check(L.lib().mh_transpose16(p(x), i64(ldi), p(out), i64(_rowmajor(out)), i32(R), i32(Cc), i32(r_pad), _stream()), "mh_transpose16")
+    return out
+
+
+def rmsnorm_fwd(x, w, eps, out=None):
+    rows, d = x.shape
+    assert x.is_contiguous() and w.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().mh_rmsnorm_fwd(p(x), p(w), p(out), p(None), i32(rows), i32(d), f32(eps), i32(dt_of(x)), _stream()), "mh_rmsnorm_fwd")
+    return out
+
+
+def norm_partials(rows: int) -> int:
+    return int(L.lib().mh_norm_bwd_partials(i32(rows)))
+
+
+def reduce_partials(partial, nblk, d, out, accumulate):
+    L.check(L.lib().mh_reduce_partials(p(partial), i32(nblk), i32(d), p(out), i32(dt_of(out)), i32(int(accumulate)), _stream()), "mh_reduce_partials")
+
+
+def rmsnorm_bwd(x, w, dy, eps, dx=None, accumulate_dx=False, dw_out=None, dw_accumulate=False, ws=None):
+    """Returns dx; writes (or accumulates) dw into dw_out (16-bit or fp32 [d])."""
+    rows, d = x.shape
+    nblk = norm_partials(rows)
+    part = torch.empty(nblk, d, dtype=torch.float32, device=x.device) if ws is None else ws
+    dx = torch.empty_like(x) if dx is None else dx
+    L.check(L.lib().mh_rmsnorm_bwd(p(x), p(w), p(dy), p(dx), p(part), i32(rows), i32(d), f32(eps), i32(dt_of(x)),
+                                   i32(int(accumulate_dx)), _stream()), "mh_rmsnorm_bwd")
+    if dw_out is not None:
+        reduce_partials(part, nblk, d, dw_out, dw_accumulate)
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps, out=None):
+    rows, d = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().mh_layernorm_fwd(p(x), p(w), p(b), p(out), i32(rows), i32(d), f32(eps), i32(dt_of(x)), _stream()), "mh_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(x, w, dy, eps, dx=None, accumulate_dx=False, dw_out=None, db_out=None, accumulate=False):
+    rows, d = x.shape
+    nblk = norm_partials(rows)
+    pw = torch.empty(nblk, d, dtype=torch.float32, device=x.device)
+    pb = torch.empty(nblk, d, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if dx is None else dx
+    L.check(L.lib().mh_layernorm_bwd(p(x), p(w), p(dy), p(dx), p(pw), p(pb), i32(rows), i32(d), f32(eps), i32(dt_of(x)),
+                                     i32(int(accumulate_dx)), _stream()), "mh_layernorm_bwd")
+    if dw_out is not None:
+        reduce_partials(pw, nblk, d, dw_out, accumulate)
+    if db_out is not None:
+        reduce_partials(pb, nblk, d, db_out, accumulate)
+    return dx
+
+
+def colsum(x, out, accumulate=False):
+    """out[d] (+)= sum over rows of x[rows, d] (bias gradient)."""
+    rows, d = x.shape
+    nblk = norm_partials(rows)
+    part = torch.empty(nblk, d, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mh_colsum_partial(p(x), i64(_rowmajor(x)), p(part), i32(rows), i32(d), i32(dt_of(x)), _stream()), "mh_colsum_partial")
+    reduce_partials(part, nblk, d, out, accumulate)
+    return out
+
+
+def swiglu_fwd(gu, out=None):
+    rows, ff2 = gu.shape
+    ff = ff2 // 2
+    assert gu.is_contiguous()
+    out = torch.empty(rows, ff, dtype=gu.dtype, device=gu.device) if out is None else out
+    L.check(L.lib().mh_swiglu_fwd(p(gu), p(out), i32(rows), i32(ff), i32(dt_of(gu)), _stream()), "mh_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu, dout, dgu=None):
+    rows, ff2 = gu.shape
+    dgu = torch.empty_like(gu) if dgu is None else dgu
+    L.check(L.lib().mh_swiglu_bwd(p(gu), p(dout), p(dgu), i32(rows), i32(ff2 // 2), i32(dt_of(gu)), _stream()), "mh_swiglu_bwd")
+    return dgu
+
+
+def quick_gelu_fwd(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().mh_quick_gelu_fwd(p(x), p(out), i64(x.numel()), i32(dt_of(x)), _stream()), "mh_quick_gelu_fwd")
+    return out
+
+
+def quick_gelu_bwd(x, dy, dx=None):
+    dx = torch.empty_like(x) if dx is None else dx
+    L.check(L.lib().mh_quick_gelu_bwd(p(x), p(dy), p(dx), i64(x.numel()), i32(dt_of(x)), _stream()), "mh_quick_gelu_bwd")
+    return dx
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().mh_add(p(a), p(b), p(out), i64(a.numel()), i32(dt_of(a)), _stream()), "mh_add")
+    return out
+
+
+def convert(src, dst):
+    assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+    L.check(L.lib().mh_convert(p(src), i32(dt_of(src)), p(dst), i32(dt_of(dst)), i64(src.numel()), _stream()), "mh_convert")
+    return dst
+
+
+def fill_normal_(t, key: int, start: int = 0, sigma: float = 0.02, offset: float = 0.0):
+    assert t.is_contiguous()
+    L.check(L.lib().mh_fill_normal(p(t), i64(t.numel()), u64(key), i64(start), f32(sigma), f32(offset), i32(dt_of(t)), _stream()), "mh_fill_normal")
+    return t
+
+
+def rope_table(S, D, theta, device):
+    tab = torch.empty(S, D // 2, 2, dtype=torch.float32, device=device)
+    L.check(L.lib().mh_rope_table(p(tab), i32(S), i32(D), f32(theta), _stream()), "mh_rope_table")
+    return tab
+
+
+def rope_qk_(qkv, table, S, H, D, inverse=False):
+    """qkv [T, 3*H*D] (fused q|k|v rows) rotated in place on q and k."""
+    T = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * D
+    L.check(L.lib().mh_rope_qk(p(qkv), p(table), i32(T), i32(S), i32(H), i32(D), i32(int(inverse)), i32(dt_of(qkv)), _stream()), "mh_rope_qk")
+    return qkv
+
+
+def attn_prep_v(v, B, S, H, D, out=None):
+    """v: [B*S, H*D] view (row stride ldv) -> vt [B, H, D, S_pad] in the kernels' key order."""
+    S_pad = round_up(S, 64)
+    out = torch.empty(B, H, D, S_pad, dtype=v.dtype, device=v.device) if out is None else out
+    L.check(L.lib().mh_attn_prep_v(p(v), i64(v.stride(0)), p(out), i32(B), i32(S), i32(H), i32(D), i32(dt_of(v)), _stream()), "mh_attn_prep_v")
+    return out
+
+
+def attn_fwd(q, k, vt, B, S, H, D, causal, seqlens=None, out=None, lse=None):
+    """q, k: [B*S, H*D] views (row strides ldq/ldk); vt from attn_prep_v.  Returns (o [B*S, H*D], lse [B,H,S_pad])."""
+    out = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if out is None else out
+    lse = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device) if lse is None else lse
+    L.check(L.lib().mh_attn_fwd(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(vt), p(out), i64(out.stride(0)), p(lse),
+                                p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), i32(dt_of(q)), _stream()), "mh_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None):
+    dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
+    dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
+    dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
+    delta = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device)
+    ws = torch.empty(int(L.lib().mh_attn_bwd_ws_elems(i32(B), i32(S), i32(H), i32(D))), dtype=q.dtype, device=q.device)
+    L.check(L.lib().mh_attn_bwd(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
+                                p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
+                                p(dv), i64(dv.stride(0)), p(ws), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)),
+                                i32(dt_of(q)), _stream()), "mh_attn_bwd")
+    return dq, dk, dv
+
+
+def im2col_patches(pixels, ps, kpad, dtype):
+    N, Cc, Himg, Wimg = pixels.shape
+    assert Cc == 3 and Himg == Wimg and pixels.is_contiguous()
+    G = Himg // ps
+    cols = torch.empty(N * G * G, kpad, dtype=dtype, device=pixels.device)
+    L.check(L.lib().mh_im2col_patches(p(pixels), i32(dt_of(pixels)), p(cols), i32(N), i32(Himg), i32(ps), i32(kpad), i32(dt_of(dtype)), _stream()), "mh_im2col_patches")
+    return cols
+
+
+def vit_assemble(patch, cls, pos, N, G2):
+    d = patch.shape[1]
+    x = torch.empty(N * (G2 + 1), d, dtype=patch.dtype, device=patch.device)
+    L.check(L.lib().mh_vit_assemble(p(patch), p(cls), p(pos), p(x), i32(N), i32(G2), i32(d), i32(dt_of(patch)), _stream()), "mh_vit_assemble")
+    return x
+
+
+def splice_index(ids, img_offset, P, im_patch, im_start, im_end, err):
+    B, S = ids.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    src = torch.empty(B, S, dtype=torch.int32, device=ids.device)
+    L.check(L.lib().mh_splice_index(p(ids), p(img_offset), p(src), p(err), i32(B), i32(S), i32(P), i64(im_patch), i64(im_start), i64(im_end), _stream()), "mh_splice_index")
+    return src
+
+
+def embed_splice_fwd(ids, src, embed, feats, out=None):
+    T = ids.numel()
+    d = embed.shape[1]
+    out = torch.empty(T, d, dtype=embed.dtype, device=embed.device) if out is None else out
+    L.check(L.lib().mh_embed_splice_fwd(p(ids), p(src), p(embed), p(feats), p(out), i32(T), i32(d), i32(dt_of(embed)), _stream()), "mh_embed_splice_fwd")
+    return out
+
+
+def embed_splice_bwd(ids, src, dout, dfeats, dembed32):
+    T, d = dout.shape
+    L.check(L.lib().mh_embed_splice_bwd(p(ids), p(src), p(dout), p(dfeats), p(dembed32), i32(T), i32(d), i32(dt_of(dout)), _stream()), "mh_embed_splice_bwd")
+
+
+def ce_fwd(logits, labels, V):
+    """logits fp32 [B*S, ldl]; labels int64 [B, S].  Returns (row_loss[T], lse[T], out2[2])."""
+    B, S = labels.shape
+    T = B * S
+    row_loss = torch.empty(T, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(T, dtype=torch.float32, device=logits.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().mh_ce_fwd(p(logits), i64(logits.stride(0)), p(labels), p(row_loss), p(lse), p(out2), i32(B), i32(S), i32(V), _stream()), "mh_ce_fwd")
+    return row_loss, lse, out2
+
+
+def ce_bwd(logits, labels, lse, out2, V, Vpad, gscale, dtype, out=None):
+    B, S = labels.shape
+    T = B * S
+    out = torch.empty(T, Vpad, dtype=dtype, device=logits.device) if out is None else out
+    L.check(L.lib().mh_ce_bwd(p(logits), i64(logits.stride(0)), p(labels), p(lse), p(out2), p(out), i64(out.stride(0)), i32(B), i32(S),
+                              i32(V), i32(Vpad), f32(gscale), i32(dt_of(dtype)), _stream()), "mh_ce_bwd")
+    return out
+
+
+def adamw_(param, grad, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
+    L.check(L.lib().mh_adamw(p(param), p(grad), p(m), p(v), i64(param.numel()), f32(lr), f32(beta1), f32(beta2), f32(eps), f32(wd),
+                             i32(step), f32(gscale), i32(dt_of(param)), _stream()), "mh_adamw")
+
+
+def sumsq(g, out):
+    L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")

@@ -17,10 +17,12 @@ then visible in parity tests).
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 MASK64 = (1 << 64) - 1
-_IH_STD = 65536.0 * (1.0 / 3.0) ** 0.5  # std of the sum of four U{0..65535}
+_IH_STD = 65536.0 * math.sqrt(1.0 / 3.0)  # std of the sum of four U{0..65535} (sqrt is correctly rounded: same in C)
 _IH_MEAN = 131070  # 4 * 65535 / 2
 
 

@@ -1,0 +1,361 @@
+"""Per-kernel numerics on a real MI355X: every C-ABI op vs a plain PyTorch fp32 reference of the
+same op, on inputs rounded to the 16-bit storage type (so the comparison measures the kernel, not
+the input quantisation).  Tolerances are relative to the reference's max magnitude."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+EPS16 = {torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dtype=torch.bfloat16, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def relerr(got, ref):
+    got, ref = got.float(), ref.float()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from merlin_amd import ops as O
+
+    assert O.arch_ok(0), "not a gfx950 device"
+    return O
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (613, 4096, 1024), (200, 103, 256), (577, 3072, 1024), (1000, 11008, 256), (64, 384, 640)])
+def test_gemm_plain(ops, dtype, M, N, K):
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
+    ref = a.float() @ b.float().t()
+    out = ops.gemm_nt(a, b)
+    assert out.shape == (M, N)
+    assert relerr(out, ref) < 3 * EPS16[dtype]
+    out32 = ops.gemm_nt(a, b, out_f32=True)
+    assert relerr(out32, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(ops, dtype):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide rule 16)."""
+    K = 128
+    a = torch.eye(K, dtype=dtype, device=dev())
+    b = (torch.arange(K * K, device=dev()).reshape(K, K) % 251).to(dtype)  # b[n, k]
+    out = ops.gemm_nt(a, b)  # out[m, n] = b[n, m]
+    assert torch.equal(out.float(), b.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 300, 512, 192
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.1)
+    bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
+    base = a.float() @ b.float().t()
+    tol = 4 * EPS16[dtype]
+    assert relerr(ops.gemm_nt(a, b, bias=bias), base + bias.float()) < tol
+    z = base + bias.float()
+    assert relerr(ops.gemm_nt(a, b, bias=bias, act="quick_gelu"), z * torch.sigmoid(1.702 * z)) < tol
+    assert relerr(ops.gemm_nt(a, b, bias=bias, resid=resid), z + resid.float()) < tol
+    acc = rnd(M, N, dtype=dtype, seed=4)
+    ref = acc.float() + base
+    ops.gemm_nt(a, b, out=acc, accum=True)
+    assert relerr(acc, ref) < tol
+    acc32 = torch.ones(M, N, device=dev())
+    ops.gemm_nt(a, b, out=acc32, accum=True)
+    assert relerr(acc32, base + 1) < 1e-5
+    # odd N / odd ldc scalar path
+    b2 = rnd(103, K, dtype=dtype, seed=5)
+    out = torch.zeros(M, 103, dtype=torch.float32, device=dev())
+    ops.gemm_nt(a, b2, out=out)
+    assert relerr(out, a.float() @ b2.float().t()) < 1e-5
+    # strided views (fused qkv style): A is a column slice, C a column slice
+    big = rnd(M, 3 * K, dtype=dtype, seed=6)
+    cbig = torch.zeros(M, 2 * N, dtype=dtype, device=dev())
+    ops.gemm_nt(big[:, K:2 * K], b, out=cbig[:, N:])
+    assert relerr(cbig[:, N:], big[:, K:2 * K].float() @ b.float().t()) < tol
+    assert float(cbig[:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose(ops, dtype):
+    x = rnd(613, 200, dtype=dtype)
+    out = ops.transpose16(x, r_pad=640)
+    assert out.shape == (200, 640)
+    assert torch.equal(out[:, :613], x.t())
+    assert float(out[:, 613:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(613, 4096), (37, 256), (1000, 1024), (5, 128)])
+def test_rmsnorm(ops, dtype, rows, d):
+    x, w = rnd(rows, d, dtype=dtype), (1 + 0.1 * rnd(d, dtype=dtype, seed=1).float()).to(dtype)
+    eps = 1e-6
+
+    def f(x32, w32):
+        return w32 * x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)
+
+    y = ops.rmsnorm_fwd(x, w, eps)
+    assert relerr(y, f(x.float(), w.float())) < 2 * EPS16[dtype]
+    dy = rnd(rows, d, dtype=dtype, seed=2)
+    x32, w32 = x.float().requires_grad_(), w.float().requires_grad_()
+    f(x32, w32).backward(dy.float())
+    dw = torch.zeros(d, dtype=torch.float32, device=dev())
+    dx = ops.rmsnorm_bwd(x, w, dy, eps, dw_out=dw)
+    assert relerr(dx, x32.grad) < 3 * EPS16[dtype]
+    assert relerr(dw, w32.grad) < 1e-4
+    # accumulate paths
+    dx0 = rnd(rows, d, dtype=dtype, seed=3)
+    ref = dx0.float() + x32.grad
+    ops.rmsnorm_bwd(x, w, dy, eps, dx=dx0, accumulate_dx=True, dw_out=dw, dw_accumulate=True)
+    assert relerr(dx0, ref) < 3 * EPS16[dtype]
+    assert relerr(dw, 2 * w32.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(577 * 2, 1024), (34, 128)])
+def test_layernorm(ops, dtype, rows, d):
+    x = rnd(rows, d, dtype=dtype) + 0.5
+    w, b = (1 + 0.1 * rnd(d, dtype=dtype, seed=1).float()).to(dtype), rnd(d, dtype=dtype, seed=2, scale=0.1)
+    eps = 1e-5
+    y = ops.layernorm_fwd(x, w, b, eps)
+    x32, w32, b32 = x.float().requires_grad_(), w.float().requires_grad_(), b.float().requires_grad_()
+    ref = torch.nn.functional.layer_norm(x32, (d,), w32, b32, eps)
+    assert relerr(y, ref) < 2 * EPS16[dtype]
+    dy = rnd(rows, d, dtype=dtype, seed=3)
+    ref.backward(dy.float())
+    dw = torch.zeros(d, dtype=torch.float32, device=dev())
+    db = torch.zeros(d, dtype=torch.float32, device=dev())
+    dx = ops.layernorm_bwd(x, w, dy, eps, dw_out=dw, db_out=db)
+    assert relerr(dx, x32.grad) < 3 * EPS16[dtype]
+    assert relerr(dw, w32.grad) < 1e-4
+    assert relerr(db, b32.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(ops, dtype):
+    rows, ff = 77, 512
+    gu = rnd(rows, 2 * ff, dtype=dtype)
+    g32, u32 = gu[:, :ff].float().requires_grad_(), gu[:, ff:].float().requires_grad_()
+    ref = torch.nn.functional.silu(g32) * u32
+    assert relerr(ops.swiglu_fwd(gu), ref) < 2 * EPS16[dtype]
+    dout = rnd(rows, ff, dtype=dtype, seed=1)
+    ref.backward(dout.float())
+    dgu = ops.swiglu_bwd(gu, dout)
+    assert relerr(dgu[:, :ff], g32.grad) < 3 * EPS16[dtype]
+    assert relerr(dgu[:, ff:], u32.grad) < 3 * EPS16[dtype]
+    x = rnd(rows, ff, dtype=dtype, seed=2)
+    x32 = x.float().requires_grad_()
+    r = x32 * torch.sigmoid(1.702 * x32)
+    assert relerr(ops.quick_gelu_fwd(x), r) < 2 * EPS16[dtype]
+    r.backward(dout.float())
+    assert relerr(ops.quick_gelu_bwd(x, dout), x32.grad) < 3 * EPS16[dtype]
+    assert relerr(ops.add(x, dout), x.float() + dout.float()) < 2 * EPS16[dtype]
+    s = torch.zeros(1, device=dev())
+    ops.sumsq(x, s)
+    assert abs(float(s) - float(x.float().pow(2).sum())) < 1e-3 * float(x.float().pow(2).sum())
+    y32 = torch.empty(rows, ff, device=dev())
+    ops.convert(x, y32)
+    assert torch.equal(y32, x.float())
+
+
+def test_fill_normal_matches_numpy(ops):
+    from merlin_amd import weights as W
+
+    name = "model.layers.3.mlp.up_proj.weight"
+    ref = W.generate(name, (1000, 96))
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        t = torch.empty(1000, 96, dtype=dtype, device=dev())
+        ops.fill_normal_(t, W.param_key(name, 0))
+        assert np.array_equal(t.float().cpu().numpy(), ref), dtype
+    nref = W.generate("model.norm.weight", (512,))
+    t = torch.empty(512, dtype=torch.bfloat16, device=dev())
+    ops.fill_normal_(t, W.param_key("model.norm.weight", 0), offset=1.0)
+    assert np.array_equal(t.float().cpu().numpy(), nref)
+    # start offset = slicing
+    t2 = torch.empty(96 * 10, dtype=torch.float32, device=dev())
+    ops.fill_normal_(t2, W.param_key(name, 0), start=96 * 5)
+    assert np.array_equal(t2.cpu().numpy(), ref[5:15].reshape(-1))
+
+
+def _rope_ref(x, S, theta):
+    # x [B, S, H, D] fp32; HF rotate-half
+    D = x.shape[-1]
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32, device=x.device) / D))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32, device=x.device), inv)
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos()[None, :, None, :], emb.sin()[None, :, None, :]
+    h = D // 2
+    rot = torch.cat((-x[..., h:], x[..., :h]), -1)
+    return x * cos + rot * sin
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope(ops, dtype):
+    B, S, H, D = 2, 75, 2, 128
+    qkv = rnd(B * S, 3 * H * D, dtype=dtype)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    ref = qkv.float().view(B, S, 3, H, D).clone()
+    ref[:, :, 0] = _rope_ref(ref[:, :, 0], S, 10000.0)
+    ref[:, :, 1] = _rope_ref(ref[:, :, 1], S, 10000.0)
+    orig = qkv.clone()
+    ops.rope_qk_(qkv, tab, S, H, D)
+    assert relerr(qkv.view(B, S, 3, H, D), ref) < 3 * EPS16[dtype]
+    assert torch.equal(qkv.view(B, S, 3, H, D)[:, :, 2], orig.view(B, S, 3, H, D)[:, :, 2])
+    ops.rope_qk_(qkv, tab, S, H, D, inverse=True)  # R^T R = I
+    assert relerr(qkv, orig) < 4 * EPS16[dtype]
+
+
+def _attn_ref(q, k, v, causal, lens):
+    # q,k,v [B,S,H,D] fp32 -> o [B,S,H,D], zero rows at padded queries
+    B, S, H, D = q.shape
+    qh, kh, vh = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(D)
+    mask = torch.zeros(B, 1, S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        mask |= torch.ones(S, S, dtype=torch.bool, device=q.device).triu(1)
+    ar = torch.arange(S, device=q.device)
+    keypad = ar[None, :] >= lens[:, None]
+    mask = mask | keypad[:, None, None, :]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    o = (p @ vh).permute(0, 2, 1, 3)
+    qpad = (ar[None, :] >= lens[:, None])[:, :, None, None]
+    return o.masked_fill(qpad, 0.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,D,causal,lens", [
+    (1, 128, 1, 128, True, None), (2, 613, 2, 128, True, None), (2, 300, 2, 128, True, [300, 177]),
+    (3, 577, 2, 64, False, None), (1, 17, 2, 64, False, None), (2, 40, 2, 128, True, [29, 40]), (1, 1024, 1, 128, True, None)])
+def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
+    qkv = rnd(B * S, 3 * H * D, dtype=dtype, scale=1.0)
+    q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
+    lens_t = torch.tensor(lens if lens else [S] * B, dtype=torch.int32, device=dev())
+    vt = ops.attn_prep_v(v, B, S, H, D)
+    o, lse = ops.attn_fwd(q, k, vt, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    q32, k32, v32 = (t.float().reshape(B, S, H, D).clone().requires_grad_() for t in (q, k, v))
+    ref = _attn_ref(q32, k32, v32, causal, lens_t.long())
+    assert relerr(o.view(B, S, H, D), ref) < 4 * EPS16[dtype], "forward"
+    # lse check on valid rows
+    sc = (q32.permute(0, 2, 1, 3) @ k32.permute(0, 2, 3, 1)) / math.sqrt(D)
+    ar = torch.arange(S, device=dev())
+    m = (ar[None, :] >= lens_t.long()[:, None])[:, None, None, :]
+    if causal:
+        m = m | torch.ones(S, S, dtype=torch.bool, device=dev()).triu(1)
+    lse_ref = torch.logsumexp(sc.masked_fill(m, float("-inf")), -1)
+    for b in range(B):
+        n = int(lens_t[b])
+        assert float((lse[b, :, :n] - lse_ref[b, :, :n].detach()).abs().max()) < 2e-2
+    do = rnd(B * S, H * D, dtype=dtype, seed=9)
+    do_masked = do.clone()
+    ref.backward(do.float().view(B, S, H, D))
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    tol = 8 * EPS16[dtype]
+    assert relerr(dv.view(B, S, H, D), v32.grad) < tol, "dv"
+    assert relerr(dk.view(B, S, H, D), k32.grad) < tol, "dk"
+    assert relerr(dq.view(B, S, H, D), q32.grad) < tol, "dq"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_embed_pieces(ops, dtype):
+    N, img, ps, d = 3, 56, 14, 128
+    G = img // ps
+    pix = torch.randn(N, 3, img, img, device=dev())
+    kpad = 640
+    cols = ops.im2col_patches(pix, ps, kpad, dtype)
+    ref = torch.nn.functional.unfold(pix.to(dtype).float(), ps, stride=ps).transpose(1, 2).reshape(N * G * G, 3 * ps * ps)
+    assert torch.equal(cols[:, :588].float(), ref)
+    assert float(cols[:, 588:].abs().max()) == 0.0
+    patch, cls, pos = rnd(N * G * G, d, dtype=dtype), rnd(d, dtype=dtype, seed=1), rnd(G * G + 1, d, dtype=dtype, seed=2)
+    x = ops.vit_assemble(patch, cls, pos, N, G * G)
+    r = torch.cat([cls.float().expand(N, 1, d), patch.float().view(N, G * G, d)], 1) + pos.float()[None]
+    assert relerr(x.view(N, G * G + 1, d), r) < 2 * EPS16[dtype]
+
+
+def test_splice_index_and_embed(ops):
+    V, P, d = 100, 4, 64
+    PATCH, ST, EN = V, V + 1, V + 2
+    ids = torch.tensor([[1, ST, PATCH, PATCH, PATCH, PATCH, EN, 5, 6, ST, PATCH, PATCH, PATCH, PATCH, EN, 2],
+                        [1, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 2, 0],
+                        [1, 3, ST, PATCH, PATCH, PATCH, PATCH, EN, 4, 2, 0, 0, 0, 0, 0, 0]], dtype=torch.int64, device=dev())
+    img_off = torch.tensor([0, 2, 3, 5], dtype=torch.int32, device=dev())  # sample 2 has 2 images but 1 start (extra ignored)
+    err = torch.zeros(4, dtype=torch.int32, device=dev())
+    src = ops.splice_index(ids, img_off, P, PATCH, ST, EN, err)
+    assert err.tolist()[:2] == [0, 0]
+    exp = torch.full((3, 16), -1, dtype=torch.int32)
+    exp[0, 2:6] = torch.arange(0, 4)
+    exp[0, 10:14] = torch.arange(4, 8)
+    exp[2, 3:7] = torch.arange(12, 16)  # image index 3 (offset of sample 2)
+    assert torch.equal(src.cpu(), exp)
+    # error: count mismatch
+    bad = ids.clone(); bad[0, 14] = 5
+    err.zero_(); ops.splice_index(bad, img_off, P, PATCH, ST, EN, err)
+    assert err[0].item() == 1
+    # error: misplaced end
+    bad = ids.clone(); bad[2, 7], bad[2, 8] = 4, EN
+    err.zero_(); ops.splice_index(bad, img_off, P, PATCH, ST, EN, err)
+    assert err[1].item() == 1
+    for dtype in DTYPES:
+        emb, feats = rnd(V + 3, d, dtype=dtype), rnd(5 * P, d, dtype=dtype, seed=1)
+        out = ops.embed_splice_fwd(ids, src, emb, feats)
+        ref = emb[ids.view(-1)].clone()
+        sel = src.view(-1) >= 0
+        ref[sel] = feats[src.view(-1)[sel].long()]
+        assert torch.equal(out, ref)
+        dout = rnd(48, d, dtype=dtype, seed=2)
+        dfe = torch.zeros(5 * P, d, dtype=dtype, device=dev())
+        dem = torch.zeros(V + 3, d, dtype=torch.float32, device=dev())
+        ops.embed_splice_bwd(ids, src, dout, dfe, dem)
+        rfe = torch.zeros_like(dfe); rfe[src.view(-1)[sel].long()] = dout[sel]
+        assert torch.equal(dfe, rfe)
+        rem = torch.zeros_like(dem); rem.index_add_(0, ids.view(-1)[~sel], dout[~sel].float())
+        assert relerr(dem, rem) < 1e-6
+
+
+@pytest.mark.parametrize("V", [103, 32003])
+def test_cross_entropy(ops, V):
+    B, S = 2, 37
+    Vpad = (V + 63) // 64 * 64
+    logits = torch.randn(B * S, Vpad, device=dev()) * 3
+    labels = torch.randint(0, V, (B, S), device=dev())
+    labels[0, :5] = -100
+    labels[1, 10:20] = -100
+    row_loss, lse, out2 = ops.ce_fwd(logits, labels, V)
+    lg = logits[:, :V].view(B, S, V).clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+    loss = out2[0] / out2[1]
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert float(out2[1]) == float((labels[:, 1:] != -100).sum())
+    ref.backward()
+    for dtype in DTYPES:
+        dl = ops.ce_bwd(logits, labels, lse, out2, V, Vpad, 1.0, dtype)
+        assert relerr(dl[:, :V].view(B, S, V), lg.grad) < 2 * EPS16[dtype]
+        assert float(dl[:, V:].abs().max()) == 0.0 if Vpad > V else True
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adamw(ops, dtype):
+    n = 4096
+    p0, g = rnd(n, dtype=dtype), rnd(n, dtype=dtype, seed=1, scale=0.01)
+    ref = p0.float().clone().requires_grad_()
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    p = p0.clone()
+    for step in range(1, 4):
+        ref.grad = g.float()
+        opt.step()
+        ops.adamw_(p, g, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.1, step)
+    assert relerr(p, ref.detach()) < 6 * EPS16[dtype]

@@ -133,9 +133,15 @@ int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x
  * sample b is one of the P rows after an <im_start>, else -1 (use embed_tokens[ids]).
  * img_offset int32[B+1]: exclusive prefix sum of images per sample.  err int32[4] (device):
  * err[0] != 0 on <im_start>/<im_end> count mismatch (base_mmgpt.py:116-118), err[1] != 0 when
- * <im_end> is not at start+P+1 (base_mmgpt.py:125-126); err[2], err[3] = (sample, position). */
+ * <im_end> is not at start+P+1 (base_mmgpt.py:125-126); err[2], err[3] = (sample, position).
+ * Feature row of patch j of global image g is g*rows_per_img + row0 + j (rows_per_img=577,row0=1
+ * lets the projector run on the tower output with its CLS rows in place: no drop-CLS copy). */
 int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src, int32_t* err,
-                    int B, int S, int P, int64_t im_patch, int64_t im_start, int64_t im_end, void* stream);
+                    int B, int S, int P, int64_t im_patch, int64_t im_start, int64_t im_end,
+                    int rows_per_img, int row0, void* stream);
+/* lens[b] = 1 + last s with mask[b, s] != 0 (mask: bool/uint8 [B, S]); the collator's right-padded
+ * attention_mask (collator.py:32) -> per-sample lengths = flash-attn's cu_seqlens */
+int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream);
 int mh_embed_splice_fwd(const int64_t* ids, const int32_t* src, const void* embed, const void* feats,
                         void* out, int T, int d, int dt, void* stream);
 /* dfeats[src] = dout rows (pure copy; rows never collide); dembed32[ids] += dout (fp32 atomics) */
@@ -145,7 +151,8 @@ int mh_embed_splice_bwd(const int64_t* ids, const int32_t* src, const void* dout
 /* ---- shifted cross-entropy (llama_mmgpt.py:92-100) -------------------------------------- */
 /* logits fp32 [B*S, ldl]; labels int64 [B, S].  Row (b,s) is scored against labels[b, s+1]
  * (ignored when s == S-1 or label == -100).  Writes row_loss[T] (0 for ignored), lse[T];
- * out2[0] = sum of losses, out2[1] = number of scored rows (fp32), via a final 1-block reduce. */
+ * out[0] = sum of losses, out[1] = number of scored rows, out[2] = mean (fp32[4]), via a final
+ * 1-block reduce (deterministic). */
 int mh_ce_fwd(const float* logits, int64_t ldl, const int64_t* labels, float* row_loss, float* lse, float* out2,
               int B, int S, int V, void* stream);
 /* dlogits[t, v] (dt, ld = lddl, zero for v in [V, Vpad)) = gscale/count * (softmax - onehot) */

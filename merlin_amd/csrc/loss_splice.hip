@@ -76,6 +76,7 @@ __global__ __launch_bounds__(1024) void ce_reduce_k(const float* __restrict__ ro
     for (int w = 0; w < 16; ++w) { A += sl[w]; C += sc[w]; }
     out2[0] = A;
     out2[1] = C;
+    out2[2] = A / C;  // mean CE; NaN when no label is scored, like torch's CrossEntropyLoss
   }
 }
 
@@ -105,7 +106,7 @@ constexpr int MAX_STARTS = 1024;
 
 __global__ __launch_bounds__(256) void splice_index_k(const int64_t* __restrict__ ids, const int32_t* __restrict__ img_offset,
                                                       int32_t* __restrict__ src, int32_t* __restrict__ err, int S, int P,
-                                                      int64_t im_patch, int64_t im_start, int64_t im_end) {
+                                                      int64_t im_patch, int64_t im_start, int64_t im_end, int rows_per_img, int row0) {
   __shared__ int cnt_start[256], cnt_end[256], cnt_patch[256];
   __shared__ int start_pos[MAX_STARTS];
   __shared__ int tot[3];
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void splice_index_k(const int64_t* __restrict_
   const int base = img_offset[b];
   for (int i = tid; i < n_use * P; i += 256) {
     const int k = i / P, j = i - k * P;
-    srow[start_pos[k] + 1 + j] = (base + k) * P + j;
+    srow[start_pos[k] + 1 + j] = (base + k) * rows_per_img + row0 + j;
   }
 }
 
@@ -198,6 +199,20 @@ __global__ __launch_bounds__(256) void embed_splice_bwd_k(const int64_t* __restr
       for (int k = 0; k < 8; ++k) atomicAdd(dst + k, f[k]);
     }
   }
+}
+
+// lens[b] = 1 + last position whose mask byte is non-zero (right-padded key_padding_mask -> length)
+__global__ __launch_bounds__(256) void mask_lens_k(const uint8_t* __restrict__ mask, int32_t* __restrict__ lens, int S) {
+  __shared__ int best[4];
+  const int b = blockIdx.x;
+  int m = 0;
+  for (int s = threadIdx.x; s < S; s += 256)
+    if (mask[(int64_t)b * S + s]) m = max(m, s + 1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) lens[b] = max(max(best[0], best[1]), max(best[2], best[3]));
 }
 
 inline int grid_for(int64_t n) {
@@ -249,9 +264,15 @@ extern "C" int mh_ce_bwd(const float* logits, int64_t ldl, const int64_t* labels
 }
 
 extern "C" int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src, int32_t* err, int B, int S, int P,
-                               int64_t im_patch, int64_t im_start, int64_t im_end, void* stream) {
-  if (!ids || !img_offset || !src || !err || B <= 0 || S <= 0 || P <= 0) return MH_ERR_ARG;
-  hipLaunchKernelGGL(splice_index_k, dim3(B), dim3(256), 0, as_stream(stream), ids, img_offset, src, err, S, P, im_patch, im_start, im_end);
+                               int64_t im_patch, int64_t im_start, int64_t im_end, int rows_per_img, int row0, void* stream) {
+  if (!ids || !img_offset || !src || !err || B <= 0 || S <= 0 || P <= 0 || rows_per_img < row0 + P) return MH_ERR_ARG;
+  hipLaunchKernelGGL(splice_index_k, dim3(B), dim3(256), 0, as_stream(stream), ids, img_offset, src, err, S, P, im_patch, im_start, im_end, rows_per_img, row0);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream) {
+  if (!mask_u8 || !lens || B <= 0 || S <= 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(mask_lens_k, dim3(B), dim3(256), 0, as_stream(stream), (const uint8_t*)mask_u8, lens, S);
   MH_LAUNCH_CHECK();
 }
 

@@ -1,0 +1,597 @@
+"""The hot path: MMGPTLlamaForCausalLM forward + backward as a hand-scheduled sequence of HIP
+kernels (include/merlin_hip.h) over the flat parameter arena.  No autograd graph, no torch math:
+torch supplies device memory and the stream.
+
+Forward (reference call chain -> here):
+  llama_mmgpt.py:72   prepare_inputs_labels_for_multimodal -> tower() + projector() + splice()
+  clip_encoder.py:74-82 / HF CLIPVisionModel            -> tower()   (im2col+GEMM, LN, 23 layers)
+  mlp_projector.py:19-23 / conv_projector.py:23-39      -> projector()
+  base_mmgpt.py:99-160                                  -> splice()  (index kernel + one gather)
+  llama_mmgpt.py:75   LlamaModel (32 x decoder layer)   -> llama_layer_fwd()
+  llama_flash_attn_monkey_patch.py:20-103               -> fused QKV GEMM + RoPE + flash attention
+  llama_mmgpt.py:87-100 lm_head + shifted CE            -> head_loss()
+Backward mirrors it layer by layer.  Each decoder / encoder layer keeps only its input; the layer
+forward is recomputed inside the backward (the reference trains with --gradient_checkpointing True,
+pretrain.sh:31), or, with `save_activations=True`, kept resident (288 GB HBM makes that affordable).
+Weight gradients are written straight into the gradient arena (fused accumulate in the GEMM
+epilogue); `on_grads_ready(name_list)` fires per layer so the data-parallel all-reduce of that bucket
+overlaps the rest of the backward (merlin_amd/dp.py).
+"""
+from __future__ import annotations
+
+import math
+import weakref
+
+import torch
+
+from .. import ops as O
+from .arena import Arena
+
+VT = "model.vision_tower.vision_tower.vision_model."
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class _LlamaLayerW:
+    __slots__ = ("wqkv", "wo", "wgu", "wd", "ln1", "ln2", "names", "p")
+
+
+class _VitLayerW:
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "ln1w", "ln1b", "ln2w", "ln2b", "names", "p")
+
+
+class HipEngine:
+    def __init__(self, model):
+        self._model = weakref.ref(model)
+        self.arena = None
+        self._arena_sig = None
+        self.rope = None
+        self.save_activations = False
+        self.on_grads_ready = None  # callable(list_of_param_names) | None
+        self.strict_checks = True
+        self._err = None
+
+    # ------------------------------------------------------------------------------------------
+    # parameter arena
+    # ------------------------------------------------------------------------------------------
+    @property
+    def model(self):
+        return self._model()
+
+    def _ordered_params(self):
+        m = self.model
+        named = dict(m.named_parameters())
+        order = []
+        cfg = m.config
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            order += [p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight",
+                      p + "self_attn.o_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight",
+                      p + "mlp.down_proj.weight", p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
+        order += ["model.norm.weight", "model.embed_tokens.weight", "lm_head.weight"]
+        if any(k.startswith(VT) for k in named):
+            vt = m.get_model().vision_tower
+            for i in range(vt.config.num_hidden_layers):
+                p = VT + f"encoder.layers.{i}."
+                order += [p + f"self_attn.{n}_proj.weight" for n in ("q", "k", "v")]
+                order += [p + f"self_attn.{n}_proj.bias" for n in ("q", "k", "v")]
+                order += [p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias",
+                          p + "layer_norm1.weight", p + "layer_norm1.bias", p + "layer_norm2.weight", p + "layer_norm2.bias",
+                          p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "mlp.fc2.weight", p + "mlp.fc2.bias"]
+            order += [VT + "embeddings.class_embedding", VT + "embeddings.patch_embedding.weight",
+                      VT + "embeddings.position_embedding.weight", VT + "pre_layrnorm.weight", VT + "pre_layrnorm.bias",
+                      VT + "post_layernorm.weight", VT + "post_layernorm.bias"]
+        rest = [k for k in named if k not in set(order)]
+        order += rest
+        missing = [k for k in order if k not in named]
+        if missing:
+            raise RuntimeError(f"parameters expected by the HIP engine are missing: {missing[:4]}...")
+        return [(k, named[k]) for k in order]
+
+    def ensure_arena(self):
+        m = self.model
+        sig = tuple(id(p) for _, p in m.named_parameters())
+        if self.arena is None or self._arena_sig != sig:
+            cfg = m.config
+            vpad = _ru(cfg.vocab_size, 64)
+            self.arena = Arena(self._ordered_params(), alloc_numel={"lm_head.weight": vpad * cfg.hidden_size})
+            self._arena_sig = sig
+            self._bind = None
+        if self.arena.ensure_packed() or self._bind is None:
+            self._bind_views()
+        return self.arena
+
+    def _bind_views(self):
+        """Fused weight views (q|k|v, gate|up) over the arena."""
+        m, A = self.model, self.arena
+        cfg = m.config
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        self.llama = []
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            W = _LlamaLayerW()
+            W.p = p
+            W.wqkv = A.span(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d))
+            W.wo = A.view(p + "self_attn.o_proj.weight", shape=(d, d))
+            W.wgu = A.span(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d))
+            W.wd = A.view(p + "mlp.down_proj.weight", shape=(d, ff))
+            W.ln1 = A.view(p + "input_layernorm.weight")
+            W.ln2 = A.view(p + "post_attention_layernorm.weight")
+            W.names = [n for n in A.names if n.startswith(p)]
+            self.llama.append(W)
+        self.vit = []
+        tower = getattr(m.get_model(), "vision_tower", None)
+        if tower is not None:
+            vc = tower.config
+            vd, vff = vc.hidden_size, vc.intermediate_size
+            for i in range(vc.num_hidden_layers):
+                p = VT + f"encoder.layers.{i}."
+                W = _VitLayerW()
+                W.p = p
+                W.wqkv = A.span(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd))
+                W.bqkv = A.span(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,))
+                W.wo, W.bo = A.view(p + "self_attn.out_proj.weight", shape=(vd, vd)), A.view(p + "self_attn.out_proj.bias")
+                W.w1, W.b1 = A.view(p + "mlp.fc1.weight", shape=(vff, vd)), A.view(p + "mlp.fc1.bias")
+                W.w2, W.b2 = A.view(p + "mlp.fc2.weight", shape=(vd, vff)), A.view(p + "mlp.fc2.bias")
+                W.ln1w, W.ln1b = A.view(p + "layer_norm1.weight"), A.view(p + "layer_norm1.bias")
+                W.ln2w, W.ln2b = A.view(p + "layer_norm2.weight"), A.view(p + "layer_norm2.bias")
+                W.names = [n for n in A.names if n.startswith(p)]
+                self.vit.append(W)
+        self._bind = True
+        self.rope = None
+
+    def _trainable(self, name):
+        return self.arena.params[name].requires_grad
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------
+    def _rope_table(self, S, device):
+        cfg = self.model.config
+        if self.rope is None or self.rope.shape[0] < S or self.rope.device != device:
+            # computed on the host exactly like transformers' LlamaRotaryEmbedding (fp32), then uploaded:
+            # init-time plumbing; mh_rope_table is the device-side equivalent (tests compare them)
+            D = cfg.head_dim
+            n = max(S, 64)
+            inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+            fr = torch.outer(torch.arange(n, dtype=torch.float32), inv)
+            self.rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(device)
+        return self.rope
+
+    def _wgrad(self, dy, x, gout, fresh, Tpad):
+        """gout[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in]  (both re-laid out K=T contiguous)."""
+        dyT = O.transpose16(dy, r_pad=Tpad)
+        xT = O.transpose16(x, r_pad=Tpad)
+        O.gemm_nt(dyT, xT, out=gout, accum=not fresh)
+
+    def _ready(self, names):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(names)
+
+    # ------------------------------------------------------------------------------------------
+    # vision tower
+    # ------------------------------------------------------------------------------------------
+    def _vit_layer_fwd(self, W, x, N, S, vc, keep):
+        H = vc.num_attention_heads
+        vd = vc.hidden_size
+        D = vd // H
+        eps = vc.layer_norm_eps
+        h1 = O.layernorm_fwd(x, W.ln1w, W.ln1b, eps)
+        qkv = O.gemm_nt(h1, W.wqkv, bias=W.bqkv)
+        q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
+        vt = O.attn_prep_v(v, N, S, H, D)
+        o, lse = O.attn_fwd(q, k, vt, N, S, H, D, causal=False)
+        x2 = O.gemm_nt(o, W.wo, bias=W.bo, resid=x)
+        h2 = O.layernorm_fwd(x2, W.ln2w, W.ln2b, eps)
+        if keep:
+            f1 = O.gemm_nt(h2, W.w1, bias=W.b1)
+            a = O.quick_gelu_fwd(f1)
+        else:
+            f1 = None
+            a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
+        y = O.gemm_nt(a, W.w2, bias=W.b2, resid=x2)
+        return y, ((h1, qkv, o, lse, x2, h2, f1, a) if keep else None)
+
+    def _vit_layer_bwd(self, W, x, dy, N, S, vc, saved, fresh):
+        A = self.arena
+        H = vc.num_attention_heads
+        vd = vc.hidden_size
+        D = vd // H
+        eps = vc.layer_norm_eps
+        if saved is None:
+            _, saved = self._vit_layer_fwd(W, x, N, S, vc, keep=True)
+        h1, qkv, o, lse, x2, h2, f1, a = saved
+        T = x.shape[0]
+        Tpad = _ru(T, 64)
+        p = W.p
+        acc = not fresh
+        # fc2
+        da = O.gemm_nt(dy, O.transpose16(W.w2))
+        self._wgrad(dy, a, A.gview(p + "mlp.fc2.weight"), fresh, Tpad)
+        O.colsum(dy, A.gview(p + "mlp.fc2.bias"), accumulate=acc)
+        df1 = O.quick_gelu_bwd(f1, da)
+        dh2 = O.gemm_nt(df1, O.transpose16(W.w1))
+        self._wgrad(df1, h2, A.gview(p + "mlp.fc1.weight"), fresh, Tpad)
+        O.colsum(df1, A.gview(p + "mlp.fc1.bias"), accumulate=acc)
+        dx2 = O.layernorm_bwd(x2, W.ln2w, dh2, eps, dx=dy, accumulate_dx=True, dw_out=A.gview(p + "layer_norm2.weight"),
+                              db_out=A.gview(p + "layer_norm2.bias"), accumulate=acc)
+        do = O.gemm_nt(dx2, O.transpose16(W.wo))
+        self._wgrad(dx2, o, A.gview(p + "self_attn.out_proj.weight"), fresh, Tpad)
+        O.colsum(dx2, A.gview(p + "self_attn.out_proj.bias"), accumulate=acc)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
+        O.attn_bwd(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
+        dh1 = O.gemm_nt(dqkv, O.transpose16(W.wqkv))
+        self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd)), fresh, Tpad)
+        O.colsum(dqkv, A.gspan(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,)), accumulate=acc)
+        dx = O.layernorm_bwd(x, W.ln1w, dh1, eps, dx=dx2, accumulate_dx=True, dw_out=A.gview(p + "layer_norm1.weight"),
+                             db_out=A.gview(p + "layer_norm1.bias"), accumulate=acc)
+        self._ready(W.names)
+        return dx
+
+    def tower(self, images, ctx=None):
+        """list of [n_i,3,H,W] -> x [Nimg*(G2+1), vd] = hidden_states[select_layer] (CLS rows kept in place)."""
+        m = self.model
+        tower = m.get_model().vision_tower
+        vc = tower.config
+        A = self.arena
+        dt = A.flat.dtype
+        dev = A.flat.device
+        pix = torch.cat([im for im in images], dim=0).to(device=dev)
+        if pix.dtype not in (torch.float32, dt):
+            pix = pix.float()
+        pix = pix.contiguous()
+        N = pix.shape[0]
+        G = vc.image_size // vc.patch_size
+        G2 = G * G
+        S = G2 + 1
+        vd = vc.hidden_size
+        K = 3 * vc.patch_size * vc.patch_size
+        Kpad = _ru(K, 64)
+        cols = O.im2col_patches(pix, vc.patch_size, Kpad, dt)
+        wpad = torch.zeros(vd, Kpad, dtype=dt, device=dev)
+        wpad[:, :K].copy_(A.view(VT + "embeddings.patch_embedding.weight", shape=(vd, K)))  # layout plumbing (zero-pad K)
+        patch = O.gemm_nt(cols, wpad)
+        x0 = O.vit_assemble(patch, A.view(VT + "embeddings.class_embedding"), A.view(VT + "embeddings.position_embedding.weight", shape=(S, vd)), N, G2)
+        x = O.layernorm_fwd(x0, A.view(VT + "pre_layrnorm.weight"), A.view(VT + "pre_layrnorm.bias"), vc.layer_norm_eps)
+        L = tower.layers_used
+        train_tower = ctx is not None and ctx["train_tower"]
+        xs, saves = [], []
+        for i in range(L):
+            if train_tower:
+                xs.append(x)
+            x, sv = self._vit_layer_fwd(self.vit[i], x, N, S, vc, keep=train_tower and self.save_activations)
+            saves.append(sv)
+        if ctx is not None:
+            ctx.update(vit_cols=cols if train_tower else None, vit_x0=x0 if train_tower else None, vit_xs=xs, vit_saves=saves,
+                       vit_N=N, vit_S=S, vit_Kpad=Kpad)
+        return x, N, S
+
+    def tower_bwd(self, ctx, dx, fresh):
+        m = self.model
+        tower = m.get_model().vision_tower
+        vc = tower.config
+        A = self.arena
+        N, S = ctx["vit_N"], ctx["vit_S"]
+        L = tower.layers_used
+        for i in reversed(range(L)):
+            dx = self._vit_layer_bwd(self.vit[i], ctx["vit_xs"][i], dx, N, S, vc, ctx["vit_saves"][i], fresh)
+            ctx["vit_xs"][i] = None
+            ctx["vit_saves"][i] = None
+        acc = not fresh
+        vd = vc.hidden_size
+        G2 = S - 1
+        dx0 = O.layernorm_bwd(ctx["vit_x0"], A.view(VT + "pre_layrnorm.weight"), dx, vc.layer_norm_eps,
+                              dw_out=A.gview(VT + "pre_layrnorm.weight"), db_out=A.gview(VT + "pre_layrnorm.bias"), accumulate=acc)
+        d3 = dx0.view(N, S, vd)
+        # position embedding / class embedding grads: sums over images (column sums of [N, S*vd] and of the CLS rows)
+        O.colsum(dx0.view(N, S * vd), A.gview(VT + "embeddings.position_embedding.weight").view(S * vd), accumulate=acc)
+        O.colsum(d3[:, 0, :], A.gview(VT + "embeddings.class_embedding"), accumulate=acc)
+        # patch embedding weight grad: dW[vd, K] = dpatch^T @ cols
+        K = 3 * vc.patch_size * vc.patch_size
+        Kpad = ctx["vit_Kpad"]
+        dpatch = d3[:, 1:, :].contiguous().view(N * G2, vd)  # layout plumbing: drop the CLS rows
+        gw = torch.zeros(vd, Kpad, dtype=dx0.dtype, device=dx0.device)
+        Tp = _ru(N * G2, 64)
+        O.gemm_nt(O.transpose16(dpatch, r_pad=Tp), O.transpose16(ctx["vit_cols"], r_pad=Tp), out=gw)
+        g = A.gview(VT + "embeddings.patch_embedding.weight").view(vd, K)
+        if acc:
+            O.add(g, gw[:, :K].contiguous(), out=g)  # .contiguous(): layout plumbing (un-pad K)
+        else:
+            g.copy_(gw[:, :K])
+        self._ready([n for n in A.names if n.startswith(VT + "embeddings.") or n.startswith(VT + "pre_layrnorm")])
+
+    # ------------------------------------------------------------------------------------------
+    # projector
+    # ------------------------------------------------------------------------------------------
+    def projector(self, x, N, S, ctx=None):
+        """x [N*S, vd] (tower output incl. CLS rows) -> (feats2d, rows_per_img, row0, P)."""
+        m = self.model
+        proj = m.get_model().projector
+        A = self.arena
+        kind = "conv" if hasattr(proj, "conv_stride") else "mlp"
+        tower = m.get_model().vision_tower
+        cls_keep = tower.select_feature == "cls_patch"
+        if kind == "mlp":
+            feats = O.gemm_nt(x, A.view("model.projector.projector.weight"), bias=A.view("model.projector.projector.bias"))
+            if ctx is not None:
+                ctx.update(proj_in=x)
+            return feats, S, (0 if cls_keep else 1), (S if cls_keep else S - 1)
+        raise NotImplementedError("ConvProjector forward on the HIP path is not implemented yet")
+
+    def projector_bwd(self, ctx, dfeats, fresh):
+        """returns dx for the tower output ([N*S, vd])."""
+        A = self.arena
+        x = ctx["proj_in"]
+        wname, bname = "model.projector.projector.weight", "model.projector.projector.bias"
+        dx = None
+        if ctx["train_tower"]:
+            dx = O.gemm_nt(dfeats, O.transpose16(A.view(wname)))
+        if self._trainable(wname):
+            T = x.shape[0]
+            self._wgrad(dfeats, x, A.gview(wname), fresh, _ru(T, 64))
+            O.colsum(dfeats, A.gview(bname), accumulate=not fresh)
+            self._ready([wname, bname])
+        return dx
+
+    # ------------------------------------------------------------------------------------------
+    # Llama
+    # ------------------------------------------------------------------------------------------
+    def _llama_layer_fwd(self, W, x, B, S, lens, keep):
+        cfg = self.model.config
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        h1 = O.rmsnorm_fwd(x, W.ln1, eps)
+        qkv = O.gemm_nt(h1, W.wqkv)
+        O.rope_qk_(qkv, self.rope, S, H, D)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        vt = O.attn_prep_v(v, B, S, H, D)
+        o, lse = O.attn_fwd(q, k, vt, B, S, H, D, causal=True, seqlens=lens)
+        x2 = O.gemm_nt(o, W.wo, resid=x)
+        h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+        gu = O.gemm_nt(h2, W.wgu)
+        act = O.swiglu_fwd(gu)
+        y = O.gemm_nt(act, W.wd, resid=x2)
+        return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
+
+    def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):
+        cfg = self.model.config
+        A = self.arena
+        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        if saved is None:
+            _, saved = self._llama_layer_fwd(W, x, B, S, lens, keep=True)
+        h1, qkv, o, lse, x2, h2, gu, act = saved
+        T = x.shape[0]
+        Tpad = _ru(T, 64)
+        p = W.p
+        acc = not fresh
+        train = self._trainable(p + "mlp.down_proj.weight")
+        dact = O.gemm_nt(dy, O.transpose16(W.wd))
+        if train:
+            self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
+        del act
+        dgu = O.swiglu_bwd(gu, dact)
+        del dact
+        dh2 = O.gemm_nt(dgu, O.transpose16(W.wgu))
+        if train:
+            self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
+        del dgu, gu
+        dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
+                            dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
+        do = O.gemm_nt(dx2, O.transpose16(W.wo))
+        if train:
+            self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        O.attn_bwd(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
+        O.rope_qk_(dqkv, self.rope, S, H, D, inverse=True)
+        dh1 = O.gemm_nt(dqkv, O.transpose16(W.wqkv))
+        if train:
+            self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
+        dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
+                           dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
+        if train:
+            self._ready(W.names)
+        return dx
+
+    # ------------------------------------------------------------------------------------------
+    # splice / head
+    # ------------------------------------------------------------------------------------------
+    def _check_errors(self):
+        if self._err is None:
+            return
+        err, ev = self._err
+        self._err = None
+        ev.synchronize()
+        e = err.tolist()
+        if e[0]:
+            raise ValueError(f"The number of image start tokens and image end tokens should be the same (sample {e[2]}, difference {e[3]}).")
+        if e[1]:
+            raise ValueError(f"The image end token should follow the image start token (sample {e[2]}, <im_start> at {e[3]}).")
+
+    def splice_index(self, input_ids, images, P, rows_per_img, row0):
+        m = self.model
+        dev = input_ids.device
+        counts = [int(im.shape[0]) for im in images]
+        off = [0]
+        for c in counts:
+            off.append(off[-1] + c)
+        B = input_ids.shape[0]
+        off = (off + [off[-1]] * (B + 1))[: B + 1]  # fewer image entries than samples: zip() semantics
+        img_off = torch.tensor(off, dtype=torch.int32).to(dev, non_blocking=True)
+        err_dev = torch.zeros(4, dtype=torch.int32, device=dev)
+        src = O.splice_index(input_ids, img_off, P, m.im_patch_token, m.im_start_token, m.im_end_token, err_dev,
+                             rows_per_img=rows_per_img, row0=row0)
+        if self.strict_checks:
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(err_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._err = (host, ev)
+        return src
+
+    # ------------------------------------------------------------------------------------------
+    # public entry points
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input_ids, attention_mask, labels, images, inputs_embeds=None, want_grad=False, loss_only=False):
+        """Returns (loss fp32 scalar tensor | None, logits fp32 [B,S,V] view | None, ctx)."""
+        m = self.model
+        cfg = m.config
+        A = self.ensure_arena()
+        dt, dev = A.flat.dtype, A.flat.device
+        inner = m.get_model()
+        tower = getattr(inner, "vision_tower", None)
+        B, S = (input_ids.shape if input_ids is not None else inputs_embeds.shape[:2])
+        T = B * S
+        d = cfg.hidden_size
+        ctx = {"B": B, "S": S, "want_grad": want_grad}
+        ctx["train_tower"] = bool(want_grad and tower is not None and not tower.freeze_vision_tower and
+                                  any(p.requires_grad for p in tower.parameters()))
+        self._rope_table(S, dev)
+        if input_ids is not None:
+            input_ids = input_ids.to(dev).contiguous()
+        lens = None
+        if attention_mask is not None:
+            am = attention_mask.to(dev)
+            if am.dtype != torch.bool:
+                am = am != 0
+            lens = O.mask_lens(am.contiguous())
+        ctx["lens"] = lens
+        # ---- multimodal splice (base_mmgpt.py:82-165) ----
+        src = None
+        feats = None
+        use_images = tower is not None and images is not None and input_ids is not None and S != 1
+        if use_images:
+            xt, N, Sv = self.tower(images, ctx)
+            feats, rpi, row0, P = self.projector(xt, N, Sv, ctx)
+            src = self.splice_index(input_ids, images, P, rpi, row0)
+            ctx.update(src=src, n_feat_rows=feats.shape[0])
+        if inputs_embeds is not None:
+            x = inputs_embeds.to(device=dev, dtype=dt).reshape(T, d).contiguous()
+        else:
+            x = O.embed_splice_fwd(input_ids.view(-1), src.view(-1) if src is not None else None,
+                                   A.view("model.embed_tokens.weight", shape=(cfg.vocab_size, d)), feats)
+        if use_images:
+            self._check_errors()
+        ctx["ids"] = input_ids
+        del feats
+        # ---- decoder ----
+        xs, saves = [], []
+        for W in self.llama:
+            if want_grad:
+                xs.append(x)
+            x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations)
+            saves.append(sv)
+        ctx.update(xs=xs, saves=saves, x_last=x if want_grad else None)
+        hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), cfg.rms_norm_eps)
+        # ---- lm_head + shifted CE (llama_mmgpt.py:87-100) ----
+        V = cfg.vocab_size
+        Vpad = _ru(V, 64)
+        wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
+        logits = O.gemm_nt(hn, wlm, out_f32=True)  # [T, Vpad] fp32
+        loss = None
+        if labels is not None:
+            labels = labels.to(dev).contiguous()
+            row_loss, lse, out = O.ce_fwd(logits, labels, V)
+            loss = out[2]
+            ctx.update(labels=labels, ce_lse=lse, ce_out=out)
+        ctx.update(hn=hn if want_grad else None, logits=logits if want_grad else None)
+        lg = logits.view(B, S, Vpad)[:, :, :V]
+        return loss, lg, ctx
+
+    def backward(self, ctx, gscale=1.0):
+        """d(loss)/d(params) * gscale into the gradient arena (param.grad views)."""
+        m = self.model
+        cfg = m.config
+        A = self.arena
+        B, S = ctx["B"], ctx["S"]
+        T, d, V = B * S, cfg.hidden_size, cfg.vocab_size
+        Vpad = _ru(V, 64)
+        Tpad = _ru(T, 64)
+        dt = A.flat.dtype
+        fresh = A.ensure_grads()
+        acc = not fresh
+        lens = ctx["lens"]
+        # ---- head ----
+        dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
+        ctx["logits"] = None
+        wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
+        dhn = O.gemm_nt(dlogits, O.transpose16(wlm))  # [T, d]; B = W^T [d, Vpad]
+        if self._trainable("lm_head.weight"):
+            dlT = O.transpose16(dlogits, r_pad=Tpad)  # [Vpad, Tpad]
+            hnT = O.transpose16(ctx["hn"], r_pad=Tpad)
+            O.gemm_nt(dlT[:V], hnT, out=A.gview("lm_head.weight"), accum=acc)
+            del dlT, hnT
+        del dlogits
+        dx = O.rmsnorm_bwd(ctx["x_last"], A.view("model.norm.weight"), dhn, cfg.rms_norm_eps,
+                           dw_out=A.gview("model.norm.weight") if self._trainable("model.norm.weight") else None, dw_accumulate=acc)
+        self._ready(["lm_head.weight", "model.norm.weight"])
+        ctx["hn"] = ctx["x_last"] = None
+        # ---- decoder ----
+        for i in reversed(range(len(self.llama))):
+            dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
+            ctx["xs"][i] = None
+            ctx["saves"][i] = None
+        # ---- embedding + splice ----
+        src = ctx.get("src")
+        ids = ctx["ids"]
+        inner = m.get_model()
+        emb_train = ids is not None and self._trainable("model.embed_tokens.weight")
+        need_feats = src is not None and (ctx["train_tower"] or any(p.requires_grad for p in inner.projector.parameters()))
+        dfeats = torch.zeros(ctx["n_feat_rows"], d, dtype=dt, device=dx.device) if need_feats else None
+        dembed32 = torch.zeros(V, d, dtype=torch.float32, device=dx.device) if emb_train else None
+        if ids is not None and (need_feats or emb_train):
+            O.embed_splice_bwd(ids.view(-1), src.view(-1) if src is not None else None, dx, dfeats, dembed32)
+        if emb_train:
+            g = A.gview("model.embed_tokens.weight")
+            if acc:
+                tmp = torch.empty_like(g)
+                O.convert(dembed32, tmp)
+                O.add(g, tmp, out=g)
+            else:
+                O.convert(dembed32, g)
+            self._ready(["model.embed_tokens.weight"])
+        del dx
+        if need_feats:
+            dxt = self.projector_bwd(ctx, dfeats, fresh)
+            if ctx["train_tower"]:
+                self.tower_bwd(ctx, dxt, fresh)
+        # parameters this backward never touches (e.g. CLIP layers past select_layer, post_layernorm)
+        if fresh:
+            touched_prefixes = None
+            tower = getattr(inner, "vision_tower", None)
+            if tower is not None:
+                L = tower.layers_used
+                for n in A.names:
+                    if not A.params[n].requires_grad:
+                        continue
+                    dead = n.startswith(VT + "post_layernorm") or any(n.startswith(VT + f"encoder.layers.{i}.") for i in range(L, tower.config.num_hidden_layers))
+                    untrained_tower = n.startswith(VT) and not ctx["train_tower"]
+                    unused_mm = (n.startswith(VT) or n.startswith("model.projector.")) and src is None
+                    if dead or untrained_tower or unused_mm:
+                        A.gview(n).zero_()
+        self._ready(None)  # end of backward
+
+    # standalone sub-module calls (reference module surface; not used by the fused forward)
+    def tower_forward_public(self, images):
+        self.ensure_arena()
+        tower = self.model.get_model().vision_tower
+        x, N, S = self.tower(images, None)
+        vd = x.shape[1]
+        x3 = x.view(N, S, vd)
+        feats = x3 if tower.select_feature == "cls_patch" else x3[:, 1:]
+        feats = feats.to(images[0].dtype)
+        return torch.split(feats, [im.shape[0] for im in images], dim=0)
+
+    def projector_forward_public(self, features):
+        self.ensure_arena()
+        A = self.arena
+        out = []
+        for f in features:
+            f2 = f.to(A.flat.dtype).reshape(-1, f.shape[-1]).contiguous()
+            y = O.gemm_nt(f2, A.view("model.projector.projector.weight"), bias=A.view("model.projector.projector.bias"))
+            out.append(y.view(*f.shape[:-1], -1))
+        return out

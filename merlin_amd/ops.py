@@ -254,12 +254,20 @@ def vit_assemble(patch, cls, pos, N, G2):
     return x
 
 
-def splice_index(ids, img_offset, P, im_patch, im_start, im_end, err):
+def splice_index(ids, img_offset, P, im_patch, im_start, im_end, err, rows_per_img=None, row0=0):
     B, S = ids.shape
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     src = torch.empty(B, S, dtype=torch.int32, device=ids.device)
-    L.check(L.lib().mh_splice_index(p(ids), p(img_offset), p(src), p(err), i32(B), i32(S), i32(P), i64(im_patch), i64(im_start), i64(im_end), _stream()), "mh_splice_index")
+    L.check(L.lib().mh_splice_index(p(ids), p(img_offset), p(src), p(err), i32(B), i32(S), i32(P), i64(im_patch), i64(im_start), i64(im_end), i32(P if rows_per_img is None else rows_per_img), i32(row0), _stream()), "mh_splice_index")
     return src
+
+
+def mask_lens(mask):
+    B, S = mask.shape
+    assert mask.is_contiguous() and mask.element_size() == 1
+    lens = torch.empty(B, dtype=torch.int32, device=mask.device)
+    L.check(L.lib().mh_mask_lens(p(mask), p(lens), i32(B), i32(S), _stream()), "mh_mask_lens")
+    return lens
 
 
 def embed_splice_fwd(ids, src, embed, feats, out=None):
@@ -281,7 +289,7 @@ def ce_fwd(logits, labels, V):
     T = B * S
     row_loss = torch.empty(T, dtype=torch.float32, device=logits.device)
     lse = torch.empty(T, dtype=torch.float32, device=logits.device)
-    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    out2 = torch.empty(4, dtype=torch.float32, device=logits.device)
     L.check(L.lib().mh_ce_fwd(p(logits), i64(logits.stride(0)), p(labels), p(row_loss), p(lse), p(out2), i32(B), i32(S), i32(V), _stream()), "mh_ce_fwd")
     return row_loss, lse, out2
 

@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py - the hot path's headline benchmark (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step of the hot path on one synthetic interpair batch per GPU
+(BASELINE cfg 3/4: B=8 sequences x S=4096 = 6 x 336-px frames + trajectory text, ViT-L/14 + mlp
+projector + Llama-7B, random-init weights from the build's generator, bf16):
+    forward (ViT -> projector -> splice -> 32 decoder layers -> lm_head -> shifted CE)
+    + backward (all weight gradients, layer recompute as in the reference's gradient checkpointing)
+    + [N>1] bucketed RCCL all-reduce of the 14 GB gradient arena, overlapped with the backward
+    + fused AdamW over the parameter arena.
+Inputs are resident in HBM before the timed region.  value = N * B * S / (max-over-ranks step time).
+One JSON line is printed by rank 0, with `roofline` (dominant kernel = the MFMA GEMM, timed per launch with
+HIP events on the launch stream inside the timed steps) and `cpu_baseline` (the CPU oracle = a port of the
+reference's CPU forward, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md), not the 2:1-sparse figure
+
+LLAMA_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192)
+VIT_L_336 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14)
+
+
+def algorithmic_flops_fwd(B, S, n_img, vit_layers_used=23):
+    """2*MAC, causal attention at half of S^2, dead ViT layer and recompute not counted."""
+    d, ff, L, V = 4096, 11008, 32, 32003
+    llama = B * (L * (S * (8 * d * d + 6 * d * ff) + 2 * S * S * d) + 2 * S * d * V)
+    vd, vff, Sv = 1024, 4096, 577
+    per_layer = Sv * (8 * vd * vd + 4 * vd * vff) + 4 * Sv * Sv * vd
+    vit = n_img * (2 * 576 * 588 * vd + vit_layers_used * per_layer)
+    proj = n_img * 2 * 576 * vd * d
+    return llama + vit + proj
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Time the CPU oracle (oracle/ref_cpu.py, a port of the reference's CPU forward pinned to the
+    reference by golden vectors) on the host cores, on a bounded sample of the cfg-3 workload:
+    ONE sequence (S=4096, 6 frames): embed+splice, 2 of the 23 live ViT layers, 2 of the 32 decoder layers and
+    lm_head+CE are timed (fp32, all host threads) and scaled to full depth."""
+    from merlin_amd import synth
+    from oracle import ref_cpu as R
+
+    torch.manual_seed(0)
+    nthreads = torch.get_num_threads()
+    cfg = R.OracleConfig(num_hidden_layers=2, v_num_hidden_layers=3)  # select_layer=-2 -> 2 live ViT layers
+    P = {k: torch.empty(s).normal_(0, 0.02) if len(s) > 1 else torch.ones(s) for k, s in R.param_shapes(cfg).items()}
+    batch = synth.interpair_batch(B=1, S=4096)
+    t_parts = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats = R.encode_images(P, cfg, batch["images"])
+        t_parts["vit2+proj"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        x = R.splice_image_features(P, cfg, batch["input_ids"], feats)
+        t_parts["splice"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        h = R.llama_forward(P, cfg, x, batch["attention_mask"])
+        t_parts["llama2"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        logits = torch.nn.functional.linear(h, P["lm_head.weight"])
+        R.shifted_ce(logits, batch["labels"])
+        t_parts["head"] = time.perf_counter() - t0
+    full = t_parts["vit2+proj"] * 23 / 2 + t_parts["splice"] + t_parts["llama2"] * 32 / 2 + t_parts["head"]
+    return {"value": round(4096 / full, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "sample": "1 interpair sequence (S=4096, 6 frames) fp32 forward: 2/23 ViT layers + 2/32 decoder layers + lm_head+CE timed, "
+                      f"scaled to full depth ({full:.1f} s/sequence est.; parts {json.dumps({k: round(v, 2) for k, v in t_parts.items()})})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-activations", action="store_true", help="keep layer activations resident instead of recomputing")
+    ap.add_argument("--fwd-only", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from merlin_amd import ops as O
+    from merlin_amd import synth
+    from merlin_amd.dp import GradSync
+    from merlin_amd.model.llama_mmgpt import build_synthetic_model
+    from merlin_amd.optim import FusedAdamW
+
+    assert O.arch_ok(local_rank), "bench.py needs a gfx950 (MI355X) device"
+    model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
+    model.engine.save_activations = args.save_activations
+    if args.config == "cfg3":
+        B = args.batch or 8
+        batch = synth.interpair_batch(B=B, S=4096, rank=rank)
+        workload = f"interpair: B={B}/GPU x S=4096 (6 x 336px frames + trajectory text), ViT-L/14-336 + mlp projector + Llama-7B"
+    else:
+        B = 1
+        batch = synth.single_image_batch()
+        workload = "single 336px image + 32-token caption (S=613), ViT-L/14-336 + mlp projector + Llama-7B"
+    S = batch["input_ids"].shape[1]
+    n_img = sum(int(im.shape[0]) for im in batch["images"])
+    dbatch = dict(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
+                  labels=batch["labels"].to(dev), images=[im.to(dev) for im in batch["images"]])
+    opt = FusedAdamW(model.engine, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.0)
+    sync = GradSync(model.engine) if world > 1 else None
+
+    def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return model(**dbatch).loss
+        out = model(**dbatch)
+        out.loss.backward()
+        opt.step(grad_scale=(sync.grad_scale if sync else 1.0))
+        opt.zero_grad()
+        return out.loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    O.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = O.profile_stop()
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    tokens = world * B * S
+    value = tokens / (dt / args.steps)
+    fwd = algorithmic_flops_fwd(B, S, n_img)
+    useful = fwd * (1.0 if args.fwd_only else 3.0)
+    n, work, gms = prof.get("gemm_nt", (0, 0.0, 1e-9))
+    ach = work / (gms * 1e-3) / 1e12
+    line = {
+        "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
+        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
+        "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
+                   "step": "fwd only" if args.fwd_only else "fwd+bwd" + ("" if args.save_activations else " (layer recompute)") + "+allreduce+adamw",
+                   "loss": round(loss_val, 4)},
+        "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
+        "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "roofline": {"kernel": "gemm_nt_128 (bf16 MFMA GEMM)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                     "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline leg must never take the GPU number down
+            line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,7 @@ class HipEngine:
             order += [p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight",
                       p + "self_attn.o_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight",
                       p + "mlp.down_proj.weight", p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
-        order += ["model.norm.weight", "model.embed_tokens.weight", "lm_head.weight"]
+        order += ["model.norm.weight", "lm_head.weight", "model.embed_tokens.weight"]  # (norm, lm_head) = one DP bucket
         if any(k.startswith(VT) for k in named):
             vt = m.get_model().vision_tower
             for i in range(vt.config.num_hidden_layers):

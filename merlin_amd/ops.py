@@ -29,6 +29,45 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-launch timing (HIP events on the launch stream); used by bench.py's roofline leg ----
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = []
+
+
+def profile_stop():
+    """-> {kernel: (launches, total_work, total_ms)}; work = FLOPs (gemm/attn) or bytes."""
+    global _PROF
+    rec, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, work, s, e in rec or []:
+        n, w, ms = out.get(name, (0, 0.0, 0.0))
+        out[name] = (n + 1, w + work, ms + s.elapsed_time(e))
+    return out
+
+
+class _timed:
+    __slots__ = ("name", "work", "s")
+
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if _PROF is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _PROF.append((self.name, self.work, self.s, e))
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -70,8 +109,9 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
         epi |= EPI_OUT_F32
     else:
         assert out.dtype == a.dtype
-    L.check(L.lib().mh_gemm_nt(p(a), i64(lda), p(b), i64(ldb), p(out), i64(ldc), p(bias), p(resid), i64(ldr),
-                               i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm_nt")
+    with _timed("gemm_nt", 2.0 * M * N * K):
+        L.check(L.lib().mh_gemm_nt(p(a), i64(lda), p(b), i64(ldb), p(out), i64(ldc), p(bias), p(resid), i64(ldr),
+                                   i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm_nt")
     return out
 
 

@@ -34,6 +34,10 @@ def lib() -> C.CDLL:
             raise MerlinHipError(
                 f"{LIB_PATH} not found: build it with `python -m merlin_amd.csrc.build` "
                 "(hipcc --offload-arch=gfx950).  merlin_amd has no CPU fallback.")
+        # torch must load ITS HIP runtime first: if libmerlin_hip.so pulled in a second copy of libamdhip64
+        # before torch, the process would hold two runtimes and this one would see no device.
+        import torch  # noqa: F401
+
         _lib = C.CDLL(LIB_PATH)
         _lib.mh_strerror.restype = C.c_char_p
         _lib.mh_strerror.argtypes = [C.c_int]

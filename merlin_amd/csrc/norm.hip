@@ -197,10 +197,17 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x
 template <int DT>
 __global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ partial, int nblk, int d,
                                                          void* __restrict__ out, int out_dt, int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= d) return;
+  // 64 columns per block; the 4 waves split the partial rows 4 ways (fixed order: deterministic)
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * d + e];
+  if (e < d)
+    for (int b = g; b < nblk; b += 4) s += partial[(int64_t)b * d + e];
+  red[g][lane] = s;
+  __syncthreads();
+  if (g != 0 || e >= d) return;
+  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
   if (out_dt == MH_F32) {
     float* o = (float*)out;
     o[e] = accumulate ? o[e] + s : s;
@@ -298,7 +305,7 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* w, const void* dy, vo
 
 extern "C" int mh_reduce_partials(const float* partial, int nblk, int d, void* out, int dt, int accumulate, void* stream) {
   if (!partial || !out || nblk <= 0 || d <= 0) return MH_ERR_ARG;
-  const int grid = (d + 255) / 256;
+  const int grid = (d + 63) / 64;
   if (dt == MH_F16)
     hipLaunchKernelGGL(reduce_partials_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
   else

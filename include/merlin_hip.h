@@ -64,6 +64,10 @@ int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
                const void* bias, const void* resid, int64_t ldr,
                int M, int N, int K, int dt, int epilogue, void* stream);
 
+/* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip,
+ * else 128x128), 128 or 256 = force that tile. */
+void mh_gemm_force_kernel(int which);
+
 /* out[C, R_pad] = in[R, C]^T for 16-bit elements (operand re-layout for dgrad / wgrad GEMMs);
  * columns [R, R_pad) of out are zero filled so the transposed operand's K is a multiple of 64. */
 int mh_transpose16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int R_pad, void* stream);

@@ -1,0 +1,215 @@
+// gemm_nt_256: 256x256x64-tile bf16/f16 MFMA GEMM with a counted-vmcnt, two-group staggered pipeline
+// (gfx950).  See gemm.hip for what is common to both GEMM kernels (swizzle, swapped operands, epilogue).
+//
+// Geometry: 512 threads = 8 waves (wm = wave>>2 in {0,1}, wn = wave&3); a K-tile is four 16-KiB
+// half-tiles in one of two LDS stages (128 KiB): A0/A1 = A rows 0-127 / 128-255, B0/B1 likewise.  A wave
+// owns rows {wm*64..+64} of EACH A half and columns {wn*32..+32} of EACH B half: its 128x64 output is four
+// 64x32 quadrants visited per K-tile as (A0,B0) (A0,B1) (A1,B1) (A1,B0) = four phases of 16 MFMA 16x16x32,
+// with LDS fragment reads A0+B0 | B1 | A1 | none (B0 and the current A fragments stay in registers).
+//
+// Pipeline.  Every phase is two segments separated by raw s_barriers:
+//     A-seg: ds_read the phase's fragments; issue ONE half-tile of global_load_lds (2 per thread);
+//            s_waitcnt vmcnt(8)  (own loads of the half-tile the NEXT phase reads have landed; the four
+//            newest half-tiles stay in flight - never vmcnt(0) in the loop)
+//     B-seg: s_waitcnt lgkmcnt(0); 16 MFMAs
+//   The wm=1 waves run one barrier behind the wm=0 waves (one wave of each group per SIMD), so on every
+//   SIMD one wave's MFMA segment overlaps the other's LDS-read/issue segment.
+//   Load order = consumption order A0 B0 B1 A1; a half-tile's LDS slot is refilled two phases after its
+//   last read (so both groups are done with it): phase 0 issues B1(t+1), 1: A1(t+1), 2: A0(t+2), 3: B0(t+2),
+//   i.e. every load has >= 5 phases (> 1 K-tile of MFMA time) to land.
+//   RAW: a half-tile is read one phase after every thread's counted wait for it, with a barrier between.
+//   WAR: a slot is refilled >= 2 phases after its last read; reads complete (lgkmcnt(0)) in the B-seg of
+//   their own phase, and the lagging group's B-seg of phase q ends before the leading group's A-seg of q+2.
+//
+// hipcc specifics: the fragment reads are inline-asm `ds_read_b128` (hipcc would otherwise put
+// `s_waitcnt vmcnt(0)` in front of every ds_read that follows a global_load_lds, draining the pipeline),
+// so their completion is waited for by hand (lgkmcnt(0) + sched_barrier, cdna guide rule 18).
+#include "gemm_common.h"
+
+namespace mhgemm {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT>
+__device__ __forceinline__ f32x4_t mfma16v(u32x4 a, u32x4 b, f32x4_t c) {
+  if constexpr (DT == MH_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int HALF_BYTES = 128 * BK * 2;  // 16 KiB: 128 rows x 64 k
+constexpr int STAGE256 = 4 * HALF_BYTES;  // A0 A1 B0 B1
+constexpr int H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3;
+
+#define MH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define MH_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define MH_LGKM0()                                        \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+#define DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+// 4 row-fragments (i*2048 apart) of one half-tile at byte offset BASE, k-step addresses a0/a1
+#define READ_A(BASE)                                                                        \
+  do {                                                                                      \
+    DSR(af[0][0], aA0, BASE + 0);    DSR(af[0][1], aA1, BASE + 0);                          \
+    DSR(af[1][0], aA0, BASE + 2048); DSR(af[1][1], aA1, BASE + 2048);                       \
+    DSR(af[2][0], aA0, BASE + 4096); DSR(af[2][1], aA1, BASE + 4096);                       \
+    DSR(af[3][0], aA0, BASE + 6144); DSR(af[3][1], aA1, BASE + 6144);                       \
+  } while (0)
+#define READ_B(bf, BASE)                                                                    \
+  do {                                                                                      \
+    DSR(bf[0][0], aB0, BASE + 0);    DSR(bf[0][1], aB1, BASE + 0);                          \
+    DSR(bf[1][0], aB0, BASE + 2048); DSR(bf[1][1], aB1, BASE + 2048);                       \
+  } while (0)
+#define MFMA_QUAD(MH, NH, bf)                                                               \
+  do {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+          acc[MH][i][NH][j] = mfma16v<DT>(bf[j][ks], af[i][ks], acc[MH][i][NH][j]);         \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+  } while (0)
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = g.K / BK;
+
+  // staging sources: half-tile h, instruction i: 16-byte chunk qd = i*512 + tid of the half-tile's 1024
+  const uint16_t* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int qd = i * 512 + tid;
+    const int row = qd >> 3, cc = qd & 7;
+    const int c = (cc ^ ((row >> 1) & 7)) * 8;
+    src[H_A0][i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c;
+    src[H_A1][i] = g.A + (int64_t)min(m0 + 128 + row, g.M - 1) * g.lda + c;
+    src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
+    src[H_B1][i] = g.B + (int64_t)min(n0 + 128 + row, g.N - 1) * g.ldb + c;
+  }
+  // issue half-tile h of K-tile kt (kt clamped to the last tile: uniform load count; the re-loads of the
+  // tail only ever target slots nobody reads again)
+  auto issue = [&](int h, int kt) {
+    const int koff = min(kt, nk - 1) * BK;
+    char* dst = smem + (kt & 1) * STAGE256 + h * HALF_BYTES + wave * 1024;
+    glds16(src[h][0] + koff, dst);
+    glds16(src[h][1] + koff, dst + 8192);
+  };
+
+  f32x4_t acc[2][4][2][2];  // [mh][i][nh][j]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int swz = (frow >> 1) & 7;
+  const int kq = lane >> 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned a_row = lds0 + (wm * 64 + frow) * 128;  // row inside an A half-tile
+  const unsigned b_row = lds0 + (wn * 32 + frow) * 128;  // row inside a B half-tile
+  const unsigned c0 = ((0 + kq) ^ swz) << 4, c1 = ((4 + kq) ^ swz) << 4;  // k-step 0 / 1 chunk offsets
+
+  u32x4 af[4][2], b0f[2][2], b1f[2][2];
+
+  // prologue: 6 half-tiles in consumption order; A0(0), B0(0) landed for everyone before the first read
+  issue(H_A0, 0); issue(H_B0, 0); issue(H_B1, 0); issue(H_A1, 0); issue(H_A0, 1); issue(H_B0, 1);
+  MH_WAIT_VM(8);
+  MH_BAR();
+  if (wm == 1) MH_BAR();  // the wm=1 group runs one barrier behind
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned sb = (unsigned)(kt & 1) * STAGE256;
+    const unsigned aA0 = a_row + sb + c0, aA1 = a_row + sb + c1;
+    const unsigned aB0 = b_row + sb + c0, aB1 = b_row + sb + c1;
+
+    // ---- phase 0: quadrant (A0, B0) ----
+    READ_A(0);
+    READ_B(b0f, 32768);
+    issue(H_B1, kt + 1);
+    MH_WAIT_VM(8);
+    MH_BAR();
+    MH_LGKM0();
+    MFMA_QUAD(0, 0, b0f);
+    MH_BAR();
+
+    // ---- phase 1: quadrant (A0, B1) ----
+    READ_B(b1f, 49152);
+    issue(H_A1, kt + 1);
+    MH_WAIT_VM(8);
+    MH_BAR();
+    MH_LGKM0();
+    MFMA_QUAD(0, 1, b1f);
+    MH_BAR();
+
+    // ---- phase 2: quadrant (A1, B1) ----
+    READ_A(16384);
+    issue(H_A0, kt + 2);
+    MH_BAR();
+    MH_LGKM0();
+    MFMA_QUAD(1, 1, b1f);
+    MH_BAR();
+
+    // ---- phase 3: quadrant (A1, B0): operands already in registers ----
+    issue(H_B0, kt + 2);
+    MH_WAIT_VM(8);
+    MH_BAR();
+    MFMA_QUAD(1, 0, b0f);
+    MH_BAR();
+  }
+  if (wm == 0) MH_BAR();
+  MH_WAIT_VM(0);  // drain the (redundant) tail loads before the block's LDS is released
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + a * 128 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
+          const f32x4_t v = acc[a][i][b][j];
+          epi_store4<DT>(g, m, n, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_256<MH_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
+    hipFuncSetAttribute((const void*)gemm_nt_256<MH_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
+    attr_set = true;
+  }
+  const int grid = g.tiles_m * g.tiles_n;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(gemm_nt_256<MH_BF16>, dim3(grid), dim3(512), 2 * STAGE256, stream, g);
+  else
+    hipLaunchKernelGGL(gemm_nt_256<MH_F16>, dim3(grid), dim3(512), 2 * STAGE256, stream, g);
+  MH_LAUNCH_CHECK();
+}
+
+}  // namespace mhgemm

@@ -1,0 +1,101 @@
+// Shared pieces of the MFMA GEMM kernels (see gemm.hip for the design notes).
+#pragma once
+#include "mh_common.h"
+
+namespace mhgemm {
+
+struct GemmArgs {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  const uint16_t* bias;
+  const uint16_t* resid;
+  int64_t lda, ldb, ldc, ldr;
+  int M, N, K, epi, tiles_m, tiles_n, vec_ok;
+};
+
+constexpr int BK = 64;
+
+// block id -> (tm, tn)
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tm, int& tn) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int group = tile / per_group;
+  const int first_m = group * GM;
+  const int gsize = min(g.tiles_m - first_m, GM);
+  const int in_g = tile - group * per_group;
+  tm = first_m + in_g % gsize;
+  tn = in_g / gsize;
+}
+
+// epilogue for 4 consecutive n of one row m (v = fp32 accumulators)
+template <int DT>
+__device__ __forceinline__ void epi_store4(const GemmArgs& g, int m, int n, float v0, float v1, float v2, float v3) {
+  if (m >= g.M || n >= g.N) return;
+  const int epi = g.epi;
+  float v[4] = {v0, v1, v2, v3};
+  if (g.vec_ok) {
+    if (epi & MH_EPI_BIAS) {
+      const uint2 bb = *(const uint2*)(g.bias + n);
+      float b0, b1, b2, b3;
+      unpack2<DT>(bb.x, b0, b1);
+      unpack2<DT>(bb.y, b2, b3);
+      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+    }
+    if (epi & MH_EPI_QUICK_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    }
+    if (epi & MH_EPI_RESIDUAL) {
+      const uint2 rr = *(const uint2*)(g.resid + (int64_t)m * g.ldr + n);
+      float r0, r1, r2, r3;
+      unpack2<DT>(rr.x, r0, r1);
+      unpack2<DT>(rr.y, r2, r3);
+      v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+    }
+    if (epi & MH_EPI_OUT_F32) {
+      float4* dst = (float4*)((float*)g.C + (int64_t)m * g.ldc + n);
+      if (epi & MH_EPI_ACCUM) {
+        const float4 o = *dst;
+        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+      }
+      *dst = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      uint2* dst = (uint2*)((uint16_t*)g.C + (int64_t)m * g.ldc + n);
+      if (epi & MH_EPI_ACCUM) {
+        const uint2 o = *dst;
+        float o0, o1, o2, o3;
+        unpack2<DT>(o.x, o0, o1);
+        unpack2<DT>(o.y, o2, o3);
+        v[0] += o0; v[1] += o1; v[2] += o2; v[3] += o3;
+      }
+      *dst = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r >= g.N) continue;
+      float x = v[r];
+      if (epi & MH_EPI_BIAS) x += ld16<DT>(g.bias[n + r]);
+      if (epi & MH_EPI_QUICK_GELU) x = x / (1.0f + __expf(-1.702f * x));
+      if (epi & MH_EPI_RESIDUAL) x += ld16<DT>(g.resid[(int64_t)m * g.ldr + n + r]);
+      if (epi & MH_EPI_OUT_F32) {
+        float* dst = (float*)g.C + (int64_t)m * g.ldc + n + r;
+        if (epi & MH_EPI_ACCUM) x += *dst;
+        *dst = x;
+      } else {
+        uint16_t* dst = (uint16_t*)g.C + (int64_t)m * g.ldc + n + r;
+        if (epi & MH_EPI_ACCUM) x += ld16<DT>(*dst);
+        *dst = (uint16_t)st16<DT>(x);
+      }
+    }
+  }
+}
+
+// defined in gemm256.hip
+int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream);
+
+}  // namespace mhgemm

@@ -350,3 +350,8 @@ def adamw_(param, grad, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
 
 def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
+
+
+def gemm_force_kernel(which: int):
+    """0 = auto, 128 / 256 = force that tile size (tests, A/B benchmarks)."""
+    L.lib().mh_gemm_force_kernel(i32(which))

@@ -119,6 +119,8 @@ int mh_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
  * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
  * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */
 int64_t mh_attn_bwd_ws_elems(int B, int S, int H, int D);
+/* A/B switch for benchmarks: 1 (default) = separate dV and dK launches (lean kernels), 0 = one fused launch */
+void mh_attn_bwd_split(int split);
 int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                 const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta,
                 void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* ws,

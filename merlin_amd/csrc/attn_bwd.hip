@@ -22,26 +22,11 @@
 //  delta[q] = rowsum(dO o O) is produced by a small HBM-bound kernel first.
 // lse and delta are [B, H, S_pad] fp32 (S_pad = round_up(S, 64)) so per-lane float4 loads stay aligned.
 #include "mh_common.h"
+#include "attn_bwd_common.h"
+
+using namespace mhattn;
 
 namespace {
-
-struct BwdArgs {
-  const uint16_t *q, *k, *v, *o, *dout;
-  const uint16_t *qt, *dot, *kt;  // [B, H, D, S_pad] permuted transposes
-  const float* lse;
-  float* delta;
-  uint16_t *dq, *dk, *dv;
-  const int32_t* seqlens;
-  int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-  int B, S, H, S_pad;
-  float scale, scale_log2;
-};
-
-template <int D> struct RSwz;  // swizzle of a [rows][D] 16-bit tile (row = D*2 bytes)
-template <> struct RSwz<128> { static __device__ __forceinline__ int f(int row) { return row & 15; } };
-template <> struct RSwz<64> { static __device__ __forceinline__ int f(int row) { return (row >> 1) & 7; } };
-// swizzle of a [rows][32] 16-bit tile (64-byte rows, 4 chunks): 4 rows share a 256-B bank row
-__device__ __forceinline__ int tswz(int row) { return (row >> 2) & 3; }
 
 template <int DT, int D>
 __global__ __launch_bounds__(256) void delta_k(BwdArgs a) {
@@ -69,169 +54,6 @@ __global__ __launch_bounds__(256) void delta_k(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A: dK, dV
-// ------------------------------------------------------------------------------------------------
-template <int DT, int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_k(BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CPR = D / 8;                 // chunks per row-major row
-  constexpr int TILE = 32 * D * 2;           // bytes of one [32][D] (or [D][32]) tile
-  constexpr int STAGE = 4 * TILE;            // Q, dO, Q^T, dO^T
-  constexpr int KSTEPS = D / 16, DBLK = D / 32;
-  constexpr int NLD = TILE / (256 * 16);     // glds per thread per tile kind (2 for D=128, 1 for D=64)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int S = a.S;
-  const int len = a.seqlens ? min(a.seqlens[b], S) : S;
-  const int kv0 = blockIdx.x * 128;
-  const int kvrow = kv0 + wave * 32 + l31;
-  uint16_t* dkp = a.dk + ((int64_t)b * S + kvrow) * a.lddk + (int64_t)h * D;
-  uint16_t* dvp = a.dv + ((int64_t)b * S + kvrow) * a.lddv + (int64_t)h * D;
-
-  if (kv0 >= len) {
-    if (kvrow < S) {
-      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) {
-        *(uint2*)(dkp + d) = make_uint2(0, 0);
-        *(uint2*)(dvp + d) = make_uint2(0, 0);
-      }
-    }
-    return;
-  }
-
-  // K, V fragments (B operands): lane holds X[kvrow][16*ks + 8*hi .. +8]
-  uint4 kf[KSTEPS], vf[KSTEPS];
-  {
-    const int kr = min(kvrow, S - 1);
-    const uint16_t* kp = a.k + ((int64_t)b * S + kr) * a.ldk + (int64_t)h * D + 8 * hi;
-    const uint16_t* vp = a.v + ((int64_t)b * S + kr) * a.ldv + (int64_t)h * D + 8 * hi;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      kf[ks] = *(const uint4*)(kp + 16 * ks);
-      vf[ks] = *(const uint4*)(vp + 16 * ks);
-    }
-  }
-
-  const int q_begin = CAUSAL ? kv0 : 0;
-  const int ntiles = (len - q_begin + 31) / 32;
-
-  // staging sources
-  int rrow[NLD], rcol[NLD], trow[NLD], tcol[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int qd = i * 256 + tid;
-    rrow[i] = qd / CPR;
-    rcol[i] = ((qd % CPR) ^ RSwz<D>::f(rrow[i])) * 8;
-    trow[i] = qd >> 2;  // d
-    tcol[i] = ((qd & 3) ^ tswz(trow[i])) * 8;
-  }
-  const int64_t bh_t = ((int64_t)b * a.H + h) * D;
-  auto stage = [&](int s, int q0) {
-    char* base = smem + s * STAGE;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int qr = min(q0 + rrow[i], S - 1);
-      const int64_t roff = ((int64_t)b * S + qr);
-      glds16(a.q + roff * a.ldq + (int64_t)h * D + rcol[i], base + 0 * TILE + (i * 256 + wave * 64) * 16);
-      glds16(a.dout + roff * a.lddo + (int64_t)h * D + rcol[i], base + 1 * TILE + (i * 256 + wave * 64) * 16);
-      glds16(a.qt + (bh_t + trow[i]) * a.S_pad + q0 + tcol[i], base + 2 * TILE + (i * 256 + wave * 64) * 16);
-      glds16(a.dot + (bh_t + trow[i]) * a.S_pad + q0 + tcol[i], base + 3 * TILE + (i * 256 + wave * 64) * 16);
-    }
-  };
-
-  f32x16_t dvacc[DBLK], dkacc[DBLK];
-#pragma unroll
-  for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dvacc[i][r] = 0.f; dkacc[i][r] = 0.f; }
-
-  const int r_off = l31 * (D * 2);
-  const int r_swz = RSwz<D>::f(l31);
-  const float* lse_row = a.lse + ((int64_t)b * a.H + h) * a.S_pad;
-  const float* dl_row = a.delta + ((int64_t)b * a.H + h) * a.S_pad;
-  const float sc = a.scale_log2;
-
-  stage(0, q_begin);
-  for (int j = 0; j < ntiles; ++j) {
-    const int q0 = q_begin + j * 32;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (j + 1 < ntiles) stage((j + 1) & 1, q0 + 32);
-    // causal: this wave's keys all above every query of the tile -> nothing to do
-    if (CAUSAL && (kv0 + wave * 32 > q0 + 31)) continue;
-    const char* sQ = smem + (j & 1) * STAGE;
-    const char* sDO = sQ + TILE;
-    const char* sQT = sQ + 2 * TILE;
-    const char* sDOT = sQ + 3 * TILE;
-
-    f32x16_t sacc, pacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int coff = ((2 * ks + hi) ^ r_swz) << 4;
-      const uint4 qa = *(const uint4*)(sQ + r_off + coff);
-      const uint4 da = *(const uint4*)(sDO + r_off + coff);
-      sacc = mfma32<DT>(qa, kf[ks], sacc);
-      pacc = mfma32<DT>(da, vf[ks], pacc);
-    }
-    // P and dS (rows = queries live in registers: q = q0 + (r&3) + 8*(r>>2) + 4*hi)
-    float pv[16], dsv[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int qb = q0 + 8 * g + 4 * hi;
-      const float4 l4 = *(const float4*)(lse_row + qb);
-      const float4 d4 = *(const float4*)(dl_row + qb);
-      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-      const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const int q = qb + e;
-        const bool ok = (q < len) && (kvrow < len) && (!CAUSAL || kvrow <= q);
-        const float p = ok ? exp2f(sacc[r] * sc - ls[e] * 1.4426950408889634f) : 0.f;
-        pv[r] = p;
-        dsv[r] = ok ? p * (pacc[r] - dl[e]) * a.scale : 0.f;
-      }
-    }
-    uint4 pf[2], dsf[2];
-    pf[0] = pack8<DT>(pv); pf[1] = pack8<DT>(pv + 8);
-    dsf[0] = pack8<DT>(dsv); dsf[1] = pack8<DT>(dsv + 8);
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i) {
-      const int row = 32 * i + l31;
-      const int tsw = tswz(row);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int off = row * 64 + (((2 * s + hi) ^ tsw) << 4);
-        const uint4 dot_a = *(const uint4*)(sDOT + off);
-        const uint4 qt_a = *(const uint4*)(sQT + off);
-        dvacc[i] = mfma32<DT>(dot_a, pf[s], dvacc[i]);
-        dkacc[i] = mfma32<DT>(qt_a, dsf[s], dkacc[i]);
-      }
-    }
-  }
-
-  if (kvrow < S) {
-    const bool valid = kvrow < len;
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * i + 8 * g + 4 * hi;
-        uint2 wk = make_uint2(0, 0), wv = make_uint2(0, 0);
-        if (valid) {
-          wk = make_uint2(pack2<DT>(dkacc[i][4 * g + 0], dkacc[i][4 * g + 1]), pack2<DT>(dkacc[i][4 * g + 2], dkacc[i][4 * g + 3]));
-          wv = make_uint2(pack2<DT>(dvacc[i][4 * g + 0], dvacc[i][4 * g + 1]), pack2<DT>(dvacc[i][4 * g + 2], dvacc[i][4 * g + 3]));
-        }
-        *(uint2*)(dkp + d) = wk;
-        *(uint2*)(dvp + d) = wv;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Kernel B: dQ
 // ------------------------------------------------------------------------------------------------
 template <int DT, int D, bool CAUSAL>
@@ -245,8 +67,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int nq = (a.S + 127) / 128;
+  int bh_, qi;
+  if (!xcd_work(a.B * a.H, nq, bh_, qi)) return;
+  const int qblk = CAUSAL ? nq - 1 - qi : qi;
+  const int h = bh_ % a.H, b = bh_ / a.H;
   const int S = a.S;
   const int len = a.seqlens ? min(a.seqlens[b], S) : S;
   const int q0 = qblk * 128;
@@ -333,12 +158,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
       pacc = mfma32<DT>(va, dof[ks], pacc);   // dP^T[kv, q]
     }
     float dsv[16];
+    const bool need_mask = (kv0 + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kv0 + 31 > qw0));  // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const bool ok = (kv < len) && (qrow < len) && (!CAUSAL || kv <= qrow);
-      const float p = ok ? exp2f(sacc[r] * sc - lse2) : 0.f;
-      dsv[r] = ok ? p * (pacc[r] - dl) * a.scale : 0.f;
+      float p = fast_exp2(sacc[r] * sc - lse2);
+      if (need_mask) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool ok = (kv < len) && (qrow < len) && (!CAUSAL || kv <= qrow);
+        p = ok ? p : 0.f;
+      }
+      dsv[r] = (p != 0.f) ? p * (pacc[r] - dl) * a.scale : 0.f;
     }
     uint4 dsf[2];
     dsf[0] = pack8<DT>(dsv);
@@ -371,18 +200,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
 }
 
 template <int DT, int D, bool CAUSAL>
-int launch_bwd(const BwdArgs& a, hipStream_t st) {
-  constexpr size_t ldsA = 2 * 4 * (32 * D * 2), ldsB = 2 * 3 * (32 * D * 2);
+int launch_bwd(const BwdArgs& a, int dt, hipStream_t st) {
+  constexpr size_t ldsB = 2 * 3 * (32 * D * 2);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<DT, D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
     hipFuncSetAttribute((const void*)attn_bwd_dq_k<DT, D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     attr = true;
   }
   const int64_t nth = (int64_t)a.B * a.S * a.H;
   hipLaunchKernelGGL((delta_k<DT, D>), dim3((unsigned)((nth + 3) / 4)), dim3(256), 0, st, a);
-  dim3 grid((a.S + 127) / 128, a.H, a.B);
-  hipLaunchKernelGGL((attn_bwd_dkdv_k<DT, D, CAUSAL>), grid, dim3(256), ldsA, st, a);
+  const int rc = launch_attn_bwd_kv(a, dt, D, CAUSAL ? 1 : 0, st);
+  if (rc != 0) return rc;
+  dim3 grid(xcd_grid(a.B * a.H, (a.S + 127) / 128));
   hipLaunchKernelGGL((attn_bwd_dq_k<DT, D, CAUSAL>), grid, dim3(256), ldsB, st, a);
   MH_LAUNCH_CHECK();
 }
@@ -419,7 +248,7 @@ extern "C" int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ld
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2 = a.scale * 1.4426950408889634f;
   hipStream_t st = as_stream(stream);
-#define GO(DT_, D_, C_) return launch_bwd<DT_, D_, C_>(a, st)
+#define GO(DT_, D_, C_) return launch_bwd<DT_, D_, C_>(a, dt, st)
   if (dt == MH_BF16) {
     if (D == 128) { if (causal) GO(MH_BF16, 128, true); else GO(MH_BF16, 128, false); }
     else { if (causal) GO(MH_BF16, 64, true); else GO(MH_BF16, 64, false); }

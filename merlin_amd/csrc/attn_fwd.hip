@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int nq = (a.S + 127) / 128;
+  int bh, qi;
+  if (!xcd_work(a.B * a.H, nq, bh, qi)) return;
+  const int qblk = CAUSAL ? nq - 1 - qi : qi;  // causal: heaviest q-blocks first
+  const int h = bh % a.H, b = bh / a.H;
   const int S = a.S;
   const int len = a.seqlens ? min(a.seqlens[b], S) : S;
   const int q0 = qblk * 128;
@@ -172,14 +175,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs a) {
     const float m_new = fmaxf(m_run, mx * sc);
     // rows whose every key so far is masked keep m = -inf; guard the subtraction
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);
+    const float alpha = fast_exp2(m_run - m_use);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[blk][r] * sc - m_use);
+        const float p = fast_exp2(st[blk][r] * sc - m_use);
         st[blk][r] = p;
         psum += p;
       }
@@ -257,7 +260,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     hipFuncSetAttribute((const void*)attn_fwd_k<DT, D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  dim3 grid((a.S + 127) / 128, a.H, a.B);
+  dim3 grid(xcd_grid(a.B * a.H, (a.S + 127) / 128));
   hipLaunchKernelGGL((attn_fwd_k<DT, D, CAUSAL>), grid, dim3(256), lds, st, a);
   MH_LAUNCH_CHECK();
 }

@@ -18,11 +18,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // ---- 16-bit storage types: tag-dispatched conversions (DT = MH_BF16 / MH_F16) ---------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// native conversions: gfx950 has v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (round to nearest even, 2 values per
+// instruction).  A software RNE costs ~6 VALU per element and made the attention kernels VALU-bound.
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                       // round to nearest even
-  return u >> 16;
+  return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
   uint16_t s = (uint16_t)h;
@@ -40,7 +42,13 @@ template <int DT> __device__ __forceinline__ uint32_t st16(float f) {
   if constexpr (DT == MH_BF16) return f32_to_bf16_bits(f);
   else return f32_to_f16_bits(f);
 }
-template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return st16<DT>(lo) | (st16<DT>(hi) << 16); }
+template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  if constexpr (DT == MH_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+// raw v_exp_f32 (no denormal-range fix-up code): softmax arguments are <= 0, tiny results may flush to 0
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 template <int DT> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
   lo = ld16<DT>(w & 0xffffu);
   hi = ld16<DT>(w >> 16);
@@ -87,11 +95,61 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- hand-waited LDS reads ---------------------------------------------------------------------------
+// hipcc puts `s_waitcnt vmcnt(0)` in front of every ds_read it can see after a global_load_lds (it cannot
+// prove the read does not alias the in-flight LDS-DMA), which turns a prefetch into a synchronous load.
+// Fragment reads that must overlap an in-flight stage are therefore inline asm (invisible to that pass) and
+// their completion is waited for by hand: LGKM_WAIT(n) = s_waitcnt lgkmcnt(n) + sched_barrier (rule 18:
+// the MFMAs that consume the registers must not be hoisted above the wait).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read128(u32x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+#define LGKM_WAIT(N)                                             \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int DT> __device__ __forceinline__ f32x16_t mfma32v(u32x4_t a, u32x4_t b, f32x16_t c) {
+  if constexpr (DT == MH_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ u32x4_t pack8v(const float* f) {
+  u32x4_t v;
+  v[0] = pack2<DT>(f[0], f[1]); v[1] = pack2<DT>(f[2], f[3]);
+  v[2] = pack2<DT>(f[4], f[5]); v[3] = pack2<DT>(f[6], f[7]);
+  return v;
+}
+
+// async global -> LDS, 4 bytes per lane (LDS destination = wave-uniform base + lane*4)
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform `lds_base` + lane*16
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+
+// XCD-aware 1-D grid for (batch*head, chunk) work: block b runs on XCD b%8 (observed dispatch rule, used for
+// speed only).  All `nchunk` blocks of one (b,h) are given to ONE XCD, consecutively, so the K/V (or Q/dO)
+// panels they share stay in that XCD's private L2.  Grid = round_up(BH, 8) * nchunk; returns false for the
+// padding blocks.  chunk order is the dispatch order within the (b,h).
+__device__ __forceinline__ bool xcd_work(int BH, int nchunk, int& bh, int& chunk) {
+  const int id = blockIdx.x;
+  const int xcd = id & 7, idx = id >> 3;
+  bh = (idx / nchunk) * 8 + xcd;
+  chunk = idx % nchunk;
+  return bh < BH;
+}
+static inline int xcd_grid(int BH, int nchunk) { return ((BH + 7) / 8) * 8 * nchunk; }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -48,6 +48,10 @@ def bench_attn(B, S, H, D, causal):
 
 if __name__ == "__main__":
     T = 32768
+    if "attn" in sys.argv:
+        bench_attn(8, 4096, 32, 128, True)
+        bench_attn(48, 577, 16, 64, False)
+        sys.exit(0)
     for (M, N, K) in [(T, 12288, 4096), (T, 4096, 4096), (T, 22016, 4096), (T, 4096, 11008), (T, 32064, 4096),
                       (4096, 4096, 4096), (8192, 8192, 8192), (613, 12288, 4096), (27696, 3072, 1024), (27696, 4096, 1024), (27696, 1024, 4096)]:
         bench_gemm(M, N, K)

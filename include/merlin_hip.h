@@ -64,6 +64,13 @@ int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
                const void* bias, const void* resid, int64_t ldr,
                int M, int N, int K, int dt, int epilogue, void* stream);
 
+/* General form: each operand is K-contiguous (x_kstrided = 0: A[M,K] / B[N,K]) or K-strided (1: A[K,M] / B[K,N],
+ * i.e. the non-contracted index is the contiguous one).  C[M,N] = op(A) * op(B)^T as above.  Backward GEMMs need
+ * no transposed copies: dgrad dX[T,Kin] = dY[T,Nout] * W[Nout,Kin] is (A=dY, B=W K-strided); wgrad dW[Nout,Kin] =
+ * dY^T * X is (A=dY K-strided, B=X K-strided, K = T).  K-strided operands need M (resp. N) % 8 == 0. */
+int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C, int64_t ldc,
+            const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt, int epilogue, void* stream);
+
 /* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip,
  * else 128x128), 128 or 256 = force that tile. */
 void mh_gemm_force_kernel(int which);

@@ -149,8 +149,15 @@ extern "C" void mh_gemm_force_kernel(int which) { g_force_kernel = which; }
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
                           int epilogue, void* stream) {
+  return mh_gemm(A, lda, 0, B, ldb, 0, C, ldc, bias, resid, ldr, M, N, K, dt, epilogue, stream);
+}
+
+extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
+                       int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
+                       int epilogue, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
   if (K % BK != 0 || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B)) return MH_ERR_ARG;
+  if ((a_kstrided && (M & 7)) || (b_kstrided && (N & 7))) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_RESIDUAL) && !resid) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
@@ -174,10 +181,10 @@ extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
-  if (big) {
+  if (big || a_kstrided || b_kstrided) {  // K-strided operands exist only in the 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
-    return launch_gemm_nt_256(g, dt, as_stream(stream));
+    return launch_gemm_256(g, dt, a_kstrided, b_kstrided, as_stream(stream));
   } else {
     g.tiles_m = (M + BM128 - 1) / BM128;
     g.tiles_n = (N + BN128 - 1) / BN128;

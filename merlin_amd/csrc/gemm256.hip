@@ -24,6 +24,15 @@
 // hipcc specifics: the fragment reads are inline-asm `ds_read_b128` (hipcc would otherwise put
 // `s_waitcnt vmcnt(0)` in front of every ds_read that follows a global_load_lds, draining the pipeline),
 // so their completion is waited for by hand (lgkmcnt(0) + sched_barrier, cdna guide rule 18).
+//
+// Operand layouts.  Each operand is either K-contiguous (rows = m or n, the forward "NT" case) or K-STRIDED
+// (memory is [K][M] / [K][N], the non-contracted index contiguous): dgrad dX = dY * W reads W [N_out][K_in] as
+// a K-strided B, wgrad dW = dY^T * X reads both operands K-strided - no transposed copies are ever made.
+// A K-strided half-tile is staged as [64 k][128 m] (256-B rows) and its MFMA fragments are fetched with the
+// gfx950 transpose read: two `ds_read_b64_tr_b16` give a lane 8 k-values of its own m (lane i of a 16-lane group
+// supplies the address of row i>>2, columns 4*(i&3)..+3 of a 4x16 block and receives column i).  Swizzle: the
+// 32-byte column chunk is XORed with f(k) = (k&3) | ((k>>3)&1)<<2, which is a per-lane constant for the tr
+// read pattern and makes both 32-lane halves of every ds_read_b64_tr_b16 hit 8 distinct 32-B slots.
 #include "gemm_common.h"
 
 namespace mhgemm {
@@ -55,6 +64,26 @@ constexpr int H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_sched_barrier(0);                    \
   } while (0)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_read64_tr(u32x2& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// fragment i (0..NFRAG-1) x k-step ks (0..1) of a K-strided half-tile at byte offset BASE: rows k = 32*ks + 8*g +
+// (i16>>2) (+4 for the second read), per-fragment lane address at[i]
+template <int BASE, int NFRAG, typename FR>
+__device__ __forceinline__ void read_frags_tr(FR& fr, const unsigned* at) {
+#pragma unroll
+  for (int i = 0; i < NFRAG; ++i) {
+    u32x2 a0, a1, b0, b1;
+    lds_read64_tr<BASE + 0>(a0, at[i]);
+    lds_read64_tr<BASE + 1024>(a1, at[i]);
+    lds_read64_tr<BASE + 8192>(b0, at[i]);
+    lds_read64_tr<BASE + 8192 + 1024>(b1, at[i]);
+    fr[i][0] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+    fr[i][1] = u32x4{b0[0], b0[1], b1[0], b1[1]};
+  }
+}
 #define DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 // 4 row-fragments (i*2048 apart) of one half-tile at byte offset BASE, k-step addresses a0/a1
 #define READ_A(BASE)                                                                        \
@@ -79,7 +108,7 @@ constexpr int H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3;
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
 
-template <int DT>
+template <int DT, bool AKS, bool BKS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -95,17 +124,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int qd = i * 512 + tid;
-    const int row = qd >> 3, cc = qd & 7;
-    const int c = (cc ^ ((row >> 1) & 7)) * 8;
-    src[H_A0][i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c;
-    src[H_A1][i] = g.A + (int64_t)min(m0 + 128 + row, g.M - 1) * g.lda + c;
-    src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
-    src[H_B1][i] = g.B + (int64_t)min(n0 + 128 + row, g.N - 1) * g.ldb + c;
+    if constexpr (!AKS) {
+      const int row = qd >> 3, cc = qd & 7;
+      const int c = (cc ^ ((row >> 1) & 7)) * 8;
+      src[H_A0][i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c;
+      src[H_A1][i] = g.A + (int64_t)min(m0 + 128 + row, g.M - 1) * g.lda + c;
+    } else {  // [64 k][128 m]: row = k, 16 chunks per row, 32-byte chunk index swizzled by f(k)
+      const int k = qd >> 4, cc = qd & 15;
+      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+      src[H_A0][i] = g.A + (int64_t)k * g.lda + min(m0 + col, g.M - 8);
+      src[H_A1][i] = g.A + (int64_t)k * g.lda + min(m0 + 128 + col, g.M - 8);
+    }
+    if constexpr (!BKS) {
+      const int row = qd >> 3, cc = qd & 7;
+      const int c = (cc ^ ((row >> 1) & 7)) * 8;
+      src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
+      src[H_B1][i] = g.B + (int64_t)min(n0 + 128 + row, g.N - 1) * g.ldb + c;
+    } else {
+      const int k = qd >> 4, cc = qd & 15;
+      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+      src[H_B0][i] = g.B + (int64_t)k * g.ldb + min(n0 + col, g.N - 8);
+      src[H_B1][i] = g.B + (int64_t)k * g.ldb + min(n0 + 128 + col, g.N - 8);
+    }
   }
+  const int64_t a_kstep = AKS ? (int64_t)BK * g.lda : (int64_t)BK;  // elements per K-tile
+  const int64_t b_kstep = BKS ? (int64_t)BK * g.ldb : (int64_t)BK;
   // issue half-tile h of K-tile kt (kt clamped to the last tile: uniform load count; the re-loads of the
   // tail only ever target slots nobody reads again)
   auto issue = [&](int h, int kt) {
-    const int koff = min(kt, nk - 1) * BK;
+    const int64_t koff = (int64_t)min(kt, nk - 1) * (h < 2 ? a_kstep : b_kstep);
     char* dst = smem + (kt & 1) * STAGE256 + h * HALF_BYTES + wave * 1024;
     glds16(src[h][0] + koff, dst);
     glds16(src[h][1] + koff, dst + 8192);
@@ -125,9 +172,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
   const int swz = (frow >> 1) & 7;
   const int kq = lane >> 4;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned a_row = lds0 + (wm * 64 + frow) * 128;  // row inside an A half-tile
+  const unsigned a_row = lds0 + (wm * 64 + frow) * 128;  // K-contiguous: row inside an A half-tile
   const unsigned b_row = lds0 + (wn * 32 + frow) * 128;  // row inside a B half-tile
   const unsigned c0 = ((0 + kq) ^ swz) << 4, c1 = ((4 + kq) ^ swz) << 4;  // k-step 0 / 1 chunk offsets
+  // K-strided (transpose reads): lane points at row k = 8*kq + (frow>>2), columns 4*(frow&3)..+3 of its fragment
+  const unsigned t_row = lds0 + (kq * 8 + (frow >> 2)) * 256 + (frow & 3) * 8;
+  const unsigned fx = (frow >> 2) | ((kq & 1) << 2);
+  unsigned a_t[4], b_t[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_t[i] = t_row + (((wm * 4 + i) ^ fx) << 5);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_t[j] = t_row + (((wn * 2 + j) ^ fx) << 5);
 
   u32x4 af[4][2], b0f[2][2], b1f[2][2];
 
@@ -141,10 +196,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
     const unsigned sb = (unsigned)(kt & 1) * STAGE256;
     const unsigned aA0 = a_row + sb + c0, aA1 = a_row + sb + c1;
     const unsigned aB0 = b_row + sb + c0, aB1 = b_row + sb + c1;
+    unsigned atA[4], atB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atA[i] = a_t[i] + sb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) atB[j] = b_t[j] + sb;
 
     // ---- phase 0: quadrant (A0, B0) ----
-    READ_A(0);
-    READ_B(b0f, 32768);
+    if constexpr (AKS) read_frags_tr<0, 4>(af, atA); else READ_A(0);
+    if constexpr (BKS) read_frags_tr<32768, 2>(b0f, atB); else READ_B(b0f, 32768);
     issue(H_B1, kt + 1);
     MH_WAIT_VM(8);
     MH_BAR();
@@ -153,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
     MH_BAR();
 
     // ---- phase 1: quadrant (A0, B1) ----
-    READ_B(b1f, 49152);
+    if constexpr (BKS) read_frags_tr<49152, 2>(b1f, atB); else READ_B(b1f, 49152);
     issue(H_A1, kt + 1);
     MH_WAIT_VM(8);
     MH_BAR();
@@ -162,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
     MH_BAR();
 
     // ---- phase 2: quadrant (A1, B1) ----
-    READ_A(16384);
+    if constexpr (AKS) read_frags_tr<16384, 4>(af, atA); else READ_A(16384);
     issue(H_A0, kt + 2);
     MH_BAR();
     MH_LGKM0();
@@ -197,19 +257,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
 
 }  // namespace
 
-int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream) {
+template <int DT, bool AKS, bool BKS>
+int launch_one(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_256<MH_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
-    hipFuncSetAttribute((const void*)gemm_nt_256<MH_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
+    hipFuncSetAttribute((const void*)gemm_nt_256<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
     attr_set = true;
   }
-  const int grid = g.tiles_m * g.tiles_n;
-  if (dt == MH_BF16)
-    hipLaunchKernelGGL(gemm_nt_256<MH_BF16>, dim3(grid), dim3(512), 2 * STAGE256, stream, g);
-  else
-    hipLaunchKernelGGL(gemm_nt_256<MH_F16>, dim3(grid), dim3(512), 2 * STAGE256, stream, g);
+  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(512), 2 * STAGE256, stream, g);
   MH_LAUNCH_CHECK();
 }
+
+int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream) {
+  const int key = (dt == MH_BF16 ? 0 : 4) | (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
+  switch (key) {
+    case 0: return launch_one<MH_BF16, false, false>(g, stream);
+    case 1: return launch_one<MH_BF16, false, true>(g, stream);
+    case 2: return launch_one<MH_BF16, true, false>(g, stream);
+    case 3: return launch_one<MH_BF16, true, true>(g, stream);
+    case 4: return launch_one<MH_F16, false, false>(g, stream);
+    case 5: return launch_one<MH_F16, false, true>(g, stream);
+    case 6: return launch_one<MH_F16, true, false>(g, stream);
+    default: return launch_one<MH_F16, true, true>(g, stream);
+  }
+}
+
+int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream) { return launch_gemm_256(g, dt, 0, 0, stream); }
 
 }  // namespace mhgemm

@@ -161,7 +161,12 @@ class HipEngine:
         return self.rope
 
     def _wgrad(self, dy, x, gout, fresh, Tpad):
-        """gout[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in]  (both re-laid out K=T contiguous)."""
+        """gout[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in].  The contraction runs over tokens, so both operands
+        are K-strided as they lie in memory: the MFMA kernel reads them with transpose-reads, no copies.
+        (T % 64 != 0: re-lay both out with a zero-padded K instead.)"""
+        if dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+            O.gemm_nt(dy, x, a_t=True, b_t=True, out=gout, accum=not fresh)
+            return
         dyT = O.transpose16(dy, r_pad=Tpad)
         xT = O.transpose16(x, r_pad=Tpad)
         O.gemm_nt(dyT, xT, out=gout, accum=not fresh)
@@ -208,22 +213,22 @@ class HipEngine:
         p = W.p
         acc = not fresh
         # fc2
-        da = O.gemm_nt(dy, O.transpose16(W.w2))
+        da = O.gemm_nt(dy, W.w2, b_t=True)
         self._wgrad(dy, a, A.gview(p + "mlp.fc2.weight"), fresh, Tpad)
         O.colsum(dy, A.gview(p + "mlp.fc2.bias"), accumulate=acc)
         df1 = O.quick_gelu_bwd(f1, da)
-        dh2 = O.gemm_nt(df1, O.transpose16(W.w1))
+        dh2 = O.gemm_nt(df1, W.w1, b_t=True)
         self._wgrad(df1, h2, A.gview(p + "mlp.fc1.weight"), fresh, Tpad)
         O.colsum(df1, A.gview(p + "mlp.fc1.bias"), accumulate=acc)
         dx2 = O.layernorm_bwd(x2, W.ln2w, dh2, eps, dx=dy, accumulate_dx=True, dw_out=A.gview(p + "layer_norm2.weight"),
                               db_out=A.gview(p + "layer_norm2.bias"), accumulate=acc)
-        do = O.gemm_nt(dx2, O.transpose16(W.wo))
+        do = O.gemm_nt(dx2, W.wo, b_t=True)
         self._wgrad(dx2, o, A.gview(p + "self_attn.out_proj.weight"), fresh, Tpad)
         O.colsum(dx2, A.gview(p + "self_attn.out_proj.bias"), accumulate=acc)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
         O.attn_bwd(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
-        dh1 = O.gemm_nt(dqkv, O.transpose16(W.wqkv))
+        dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd)), fresh, Tpad)
         O.colsum(dqkv, A.gspan(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,)), accumulate=acc)
         dx = O.layernorm_bwd(x, W.ln1w, dh1, eps, dx=dx2, accumulate_dx=True, dw_out=A.gview(p + "layer_norm1.weight"),
@@ -328,7 +333,7 @@ class HipEngine:
         wname, bname = "model.projector.projector.weight", "model.projector.projector.bias"
         dx = None
         if ctx["train_tower"]:
-            dx = O.gemm_nt(dfeats, O.transpose16(A.view(wname)))
+            dx = O.gemm_nt(dfeats, A.view(wname), b_t=True)
         if self._trainable(wname):
             T = x.shape[0]
             self._wgrad(dfeats, x, A.gview(wname), fresh, _ru(T, 64))
@@ -369,26 +374,26 @@ class HipEngine:
         p = W.p
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
-        dact = O.gemm_nt(dy, O.transpose16(W.wd))
+        dact = O.gemm_nt(dy, W.wd, b_t=True)
         if train:
             self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
         del act
         dgu = O.swiglu_bwd(gu, dact)
         del dact
-        dh2 = O.gemm_nt(dgu, O.transpose16(W.wgu))
+        dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
         if train:
             self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
         del dgu, gu
         dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
                             dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
-        do = O.gemm_nt(dx2, O.transpose16(W.wo))
+        do = O.gemm_nt(dx2, W.wo, b_t=True)
         if train:
             self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         O.attn_bwd(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
         O.rope_qk_(dqkv, self.rope, S, H, D, inverse=True)
-        dh1 = O.gemm_nt(dqkv, O.transpose16(W.wqkv))
+        dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
             self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
         dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
@@ -519,12 +524,17 @@ class HipEngine:
         dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
         ctx["logits"] = None
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
-        dhn = O.gemm_nt(dlogits, O.transpose16(wlm))  # [T, d]; B = W^T [d, Vpad]
+        dhn = O.gemm_nt(dlogits, wlm, b_t=True)  # [T, d]; B = W^T [d, Vpad]
         if self._trainable("lm_head.weight"):
-            dlT = O.transpose16(dlogits, r_pad=Tpad)  # [Vpad, Tpad]
-            hnT = O.transpose16(ctx["hn"], r_pad=Tpad)
-            O.gemm_nt(dlT[:V], hnT, out=A.gview("lm_head.weight"), accum=acc)
-            del dlT, hnT
+            if T % 64 == 0:
+                # rows [V, Vpad) of the padded gradient block receive exact zeros (dlogits' pad columns are zero)
+                off = A.offset["lm_head.weight"]
+                O.gemm_nt(dlogits, ctx["hn"], a_t=True, b_t=True, out=A.gflat[off: off + Vpad * d].view(Vpad, d), accum=acc)
+            else:
+                dlT = O.transpose16(dlogits, r_pad=Tpad)  # [Vpad, Tpad]
+                hnT = O.transpose16(ctx["hn"], r_pad=Tpad)
+                O.gemm_nt(dlT[:V], hnT, out=A.gview("lm_head.weight"), accum=acc)
+                del dlT, hnT
         del dlogits
         dx = O.rmsnorm_bwd(ctx["x_last"], A.view("model.norm.weight"), dhn, cfg.rms_norm_eps,
                            dw_out=A.gview("model.norm.weight") if self._trainable("model.norm.weight") else None, dw_accumulate=acc)

@@ -82,11 +82,20 @@ def arch_ok(dev: int = 0) -> bool:
 
 
 # ---------------------------------------------------------------------------------------------
-def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out_f32=False, n=None):
-    """out[M,N] = a[M,K] @ b[N,K]^T (+bias)(quick_gelu)(+resid)(+out).  a, b 16-bit, row-major."""
-    M, K = a.shape
-    N = b.shape[0] if n is None else n
-    assert b.shape[1] == K and a.dtype == b.dtype
+def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out_f32=False, n=None, a_t=False, b_t=False):
+    """out[M,N] = A @ B^T (+bias)(quick_gelu)(+resid)(+out), 16-bit row-major operands.
+    A = a[M,K] (or a[K,M] when a_t: K-strided), B = b[N,K] (or b[K,N] when b_t)."""
+    if a_t:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if b_t:
+        assert b.shape[0] == K
+        N = b.shape[1] if n is None else n
+    else:
+        assert b.shape[1] == K
+        N = b.shape[0] if n is None else n
+    assert a.dtype == b.dtype
     lda, ldb = _rowmajor(a), _rowmajor(b)
     if out is None:
         assert not accum
@@ -110,8 +119,8 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
     else:
         assert out.dtype == a.dtype
     with _timed("gemm_nt", 2.0 * M * N * K):
-        L.check(L.lib().mh_gemm_nt(p(a), i64(lda), p(b), i64(ldb), p(out), i64(ldc), p(bias), p(resid), i64(ldr),
-                                   i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm_nt")
+        L.check(L.lib().mh_gemm(p(a), i64(lda), i32(int(a_t)), p(b), i64(ldb), i32(int(b_t)), p(out), i64(ldc), p(bias), p(resid),
+                                i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm")
     return out
 
 

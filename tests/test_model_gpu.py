@@ -143,6 +143,39 @@ def test_medium_backward_grad_norms_vs_reference_golden():
     assert not bad, bad[:8]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_token_count_multiple_of_64_path(dtype):
+    """B*S % 64 == 0 (like BASELINE cfg 3): the backward uses the K-strided (transpose-read) wgrad / dgrad GEMMs
+    instead of re-laid-out copies.  Interpair-style packed batch (2 frames per sequence) vs the CPU oracle."""
+    from merlin_amd import synth
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+
+    tol = TOL[dtype]
+    cfg = C.tiny_cfg()
+    batch = synth.interpair_batch(B=2, S=64, frames=2, base_vocab=cfg.vocab_size - 3, P=cfg.num_patches, image_size=cfg.v_image_size)
+    assert batch["input_ids"].shape == (2, 64)
+    model = _build(cfg, dtype)
+    out = model(**_to_dev(batch))
+    out.loss.backward()
+    P = R.make_params(cfg, seed=0, requires_grad=True)
+    loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    err = float((out.logits.float().cpu() - logits_ref.detach()).abs().max() / logits_ref.detach().abs().max())
+    assert err < tol["logits"], err
+    bad = []
+    for k, p in model.named_parameters():
+        gr = P[k].grad
+        if gr is None or float(gr.abs().max()) == 0.0 or k.endswith("self_attn.k_proj.bias"):
+            continue
+        a, b = p.grad.float().cpu().reshape(-1).double(), gr.reshape(-1).double()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        ratio = float(a.norm() / b.norm())
+        if cos < tol["cos"] or abs(ratio - 1) > tol["norm"]:
+            bad.append((k, cos, ratio))
+    assert not bad, bad[:8]
+
+
 def test_splice_errors_raise_like_reference():
     from oracle import cases as C
 

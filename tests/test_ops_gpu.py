@@ -362,6 +362,33 @@ def test_adamw(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (1000, 520, 256), (4096, 1024, 2048), (104, 2048, 128), (4096, 11008, 512)])
+def test_gemm_kstrided_operands(ops, dtype, M, N, K):
+    """Operand layouts of the backward GEMMs (no transposed copies): B K-strided (dgrad), A and B K-strided
+    (wgrad), A K-strided alone; identity x asymmetric checks catch a mis-ordered transpose read."""
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    ref = a.float() @ b.float().t()
+    at, bt = a.t().contiguous(), b.t().contiguous()  # [K, M], [K, N]
+    tol = 3 * EPS16[dtype]
+    nn = ops.gemm_nt(a, bt, b_t=True)
+    assert nn.shape == (M, N) and relerr(nn, ref) < tol, "B K-strided"
+    tn = ops.gemm_nt(at, bt, a_t=True, b_t=True)
+    assert relerr(tn, ref) < tol, "A and B K-strided"
+    tt = ops.gemm_nt(at, b, a_t=True)
+    assert relerr(tt, ref) < tol, "A K-strided"
+    for _ in range(2):
+        assert torch.equal(ops.gemm_nt(at, bt, a_t=True, b_t=True), tn)
+    acc = torch.ones(M, N, device=dev())
+    ops.gemm_nt(at, bt, a_t=True, b_t=True, out=acc, accum=True)
+    assert relerr(acc, ref + 1) < 1e-5
+    if M == K:
+        eye = torch.eye(K, dtype=dtype, device=dev())
+        asym = (torch.arange(N * K, device=dev()).reshape(K, N) % 251).to(dtype)  # B[k, n]
+        assert torch.equal(ops.gemm_nt(eye, asym, b_t=True).float(), asym.float())
+        assert torch.equal(ops.gemm_nt(eye, asym, a_t=True, b_t=True).float(), asym.float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1000, 515, 256), (613, 4096, 1024),
                                    (2048, 2048, 4096), (300, 103, 64), (4096, 11008, 512)])
 def test_gemm_256_tile_kernel(ops, dtype, M, N, K):

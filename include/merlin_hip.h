@@ -122,7 +122,7 @@ int mh_attn_prep_v(const void* v, int64_t ldv, void* vt, int B, int S, int H, in
  * causal=1: Llama (D=128), causal=0: CLIP (D=64).  scale = 1/sqrt(D). */
 int mh_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, void* o, int64_t ldo,
                 float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
-/* Backward: delta[b,h,s] = rowsum(dO*O) is computed internally into `delta` (fp32 [B,H,S_pad]).
+/* Backward: `delta` is a ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats (rowsum(dO*O), then lse*log2e).
  * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
  * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */
 int64_t mh_attn_bwd_ws_elems(int B, int S, int H, int D);

@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void delta_k(BwdArgs a) {
     acc = ld16<DT>(a.o[t * a.ldo + (int64_t)h * D + lane]) * ld16<DT>(a.dout[t * a.lddo + (int64_t)h * D + lane]);
   }
   acc = wave_sum(acc);
-  if (lane == 0) a.delta[((int64_t)b * a.H + h) * a.S_pad + s] = acc;
+  if (lane == 0) {
+    const int64_t i = ((int64_t)b * a.H + h) * a.S_pad + s;
+    a.delta[i] = acc;
+    ((float*)a.lse2)[i] = a.lse[i] * 1.4426950408889634f;  // exp2-domain log-sum-exp for the kernels below
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
   }
   const int64_t bh = (int64_t)b * a.H + h;
   const int qsafe = min(qrow, S - 1);
-  const float lse2 = a.lse[bh * a.S_pad + qsafe] * 1.4426950408889634f;
+  const float lse2 = a.lse2[bh * a.S_pad + qsafe];
   const float dl = a.delta[bh * a.S_pad + qsafe];
 
   const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
@@ -158,17 +162,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
       pacc = mfma32<DT>(va, dof[ks], pacc);   // dP^T[kv, q]
     }
     float dsv[16];
-    const bool need_mask = (kv0 + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kv0 + 31 > qw0));  // wave-uniform
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = fast_exp2(sacc[r] * sc - lse2);
-      if (need_mask) {
+    for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(fmaf(sacc[r], sc, -lse2));
+    if ((kv0 + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kv0 + 31 > qw0))) {  // wave-uniform: boundary tiles only
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const bool ok = (kv < len) && (qrow < len) && (!CAUSAL || kv <= qrow);
-        p = ok ? p : 0.f;
+        dsv[r] = ok ? dsv[r] : 0.f;
       }
-      dsv[r] = (p != 0.f) ? p * (pacc[r] - dl) * a.scale : 0.f;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsv[r] *= (pacc[r] - dl);  // softmax scale is applied once, in the epilogue
     uint4 dsf[2];
     dsf[0] = pack8<DT>(dsv);
     dsf[1] = pack8<DT>(dsv + 8);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(BwdArgs a) {
         const int d = 32 * i + 8 * g + 4 * hi;
         uint2 w = make_uint2(0, 0);
         if (valid)
-          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0], dqacc[i][4 * g + 1]), pack2<DT>(dqacc[i][4 * g + 2], dqacc[i][4 * g + 3]));
+          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0] * a.scale, dqacc[i][4 * g + 1] * a.scale), pack2<DT>(dqacc[i][4 * g + 2] * a.scale, dqacc[i][4 * g + 3] * a.scale));
         *(uint2*)(dqp + d) = w;
       }
   }
@@ -241,7 +246,7 @@ extern "C" int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ld
   if ((rc = mh_attn_prep_v(k, ldk, kt, B, S, H, D, dt, stream)) != 0) return rc;
   BwdArgs a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o;
-  a.dout = (const uint16_t*)dout; a.qt = qt; a.dot = dot; a.kt = kt; a.lse = lse; a.delta = delta;
+  a.dout = (const uint16_t*)dout; a.qt = qt; a.dot = dot; a.kt = kt; a.lse = lse; a.delta = delta; a.lse2 = delta + (int64_t)B * H * ((S + 63) / 64 * 64);
   a.dq = (uint16_t*)dq; a.dk = (uint16_t*)dk; a.dv = (uint16_t*)dv; a.seqlens = seqlens;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.B = B; a.S = S; a.H = H; a.S_pad = S_pad;

@@ -8,12 +8,13 @@ struct BwdArgs {
   const uint16_t *q, *k, *v, *o, *dout;
   const uint16_t *qt, *dot, *kt;  // [B, H, D, S_pad] permuted transposes
   const float* lse;
-  float* delta;
+  float* delta;        // [2][B, H, S_pad]: delta = rowsum(dO o O), then lse2 = lse * log2(e)
   uint16_t *dq, *dk, *dv;
   const int32_t* seqlens;
   int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int B, S, H, S_pad;
   float scale, scale_log2;
+  const float* lse2;   // = delta + B*H*S_pad (filled by delta_k)
 };
 
 template <int D> struct RSwz;  // swizzle of a [rows][D] 16-bit tile (row = D*2 bytes)

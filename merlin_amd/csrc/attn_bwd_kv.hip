@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_k(BwdArgs a) {
     tcol[i] = ((qd & 3) ^ tswz(trow[i])) * 8;
   }
   const int64_t bh_t = ((int64_t)b * a.H + h) * D;
-  const float* lse_row = a.lse + ((int64_t)b * a.H + h) * a.S_pad;
+  const float* lse_row = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;  // exp2-domain lse
   const float* dl_row = a.delta + ((int64_t)b * a.H + h) * a.S_pad;
   constexpr int OFF_LSE = NKIND * TILE;  // + wave * 256: [lse 32 f32 | delta 32 f32]
   auto stage = [&](int jt) {  // tile index jt (clamped: the tail re-loads the last tile into a dead slot)
@@ -186,27 +186,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_k(BwdArgs a) {
     }
     // ---- P and dS (query index lives in registers: q = q0 + (r&3) + 8*(r>>2) + 4*hi) ----
     float pv[16], dsv[16];
-    // masking (sequence end / diagonal) only where this wave's 32x32 block can touch it (wave-uniform)
-    const int kvw0 = kv0 + wave * 32;
-    const bool need_mask = (q0 + 32 > len) || (kvw0 + 32 > len) || (CAUSAL && (kvw0 + 31 > q0));
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const float ls = __uint_as_float(lsev[g][e]);
-        float p = fast_exp2(sacc[r] * sc - ls * 1.4426950408889634f);
-        if (need_mask) {
-          const int q = q0 + 8 * g + 4 * hi + e;
-          const bool ok = (q < len) && (kvrow < len) && (!CAUSAL || kvrow <= q);
-          p = ok ? p : 0.f;
-        }
-        pv[r] = p;
-        if constexpr (DO_DK) {
-          const float dl = __uint_as_float(dlv[g][e]);
-          dsv[r] = (p != 0.f) ? p * (pacc[r] - dl) * a.scale : 0.f;
-        }
+      for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(sacc[4 * g + e], sc, -__uint_as_float(lsev[g][e])));
+    // masking (sequence end / diagonal) only where this wave's 32x32 block can touch it (wave-uniform branch)
+    const int kvw0 = kv0 + wave * 32;
+    if ((q0 + 32 > len) || (kvw0 + 32 > len) || (CAUSAL && (kvw0 + 31 > q0))) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool ok = (q < len) && (kvrow < len) && (!CAUSAL || kvrow <= q);
+        pv[r] = ok ? pv[r] : 0.f;
       }
+    }
+    if constexpr (DO_DK) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)  // softmax scale is applied once, in the epilogue
+          dsv[4 * g + e] = pv[4 * g + e] * (pacc[4 * g + e] - __uint_as_float(dlv[g][e]));
+    }
     if constexpr (DO_DV) {
       u32x4_t pf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
       static_for<DBLK>([&](auto I) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_k(BwdArgs a) {
         const int d = 32 * i + 8 * g + 4 * hi;
         if constexpr (DO_DK) {
           uint2 w = make_uint2(0, 0);
-          if (valid) w = make_uint2(pack2<DT>(dkacc[i][4 * g + 0], dkacc[i][4 * g + 1]), pack2<DT>(dkacc[i][4 * g + 2], dkacc[i][4 * g + 3]));
+          if (valid) w = make_uint2(pack2<DT>(dkacc[i][4 * g + 0] * a.scale, dkacc[i][4 * g + 1] * a.scale), pack2<DT>(dkacc[i][4 * g + 2] * a.scale, dkacc[i][4 * g + 3] * a.scale));
           *(uint2*)(dkp + d) = w;
         }
         if constexpr (DO_DV) {

@@ -278,7 +278,7 @@ def attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=
     dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
     dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
-    delta = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device)
+    delta = torch.zeros(2, B, H, round_up(S, 64), dtype=torch.float32, device=q.device)  # [delta | lse*log2e]
     ws = torch.empty(int(L.lib().mh_attn_bwd_ws_elems(i32(B), i32(S), i32(H), i32(D))), dtype=q.dtype, device=q.device)
     L.check(L.lib().mh_attn_bwd(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
                                 p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),

@@ -172,6 +172,14 @@ def main():
     useful = fwd * (1.0 if args.fwd_only else 3.0)
     n, work, gms = prof.get("gemm_nt", (0, 0.0, 1e-9))
     ach = work / (gms * 1e-3) / 1e12
+    # HBM/fabric traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass of this same command
+    # (PMC collection cannot run inside the timed process); the committed summary is read back here.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as f:
+            traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e9, 3) if args.config == "cfg3" and not args.fwd_only else None
+    except Exception:
+        traffic = None
     line = {
         "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,7 +192,7 @@ def main():
         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": {"kernel": "gemm_nt_256/gemm_nt_128 (bf16 MFMA GEMM, all launches)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r01_gemm_traffic.json)", "launches": n,
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
     }
     if not args.no_cpu_baseline:

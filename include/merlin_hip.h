@@ -141,6 +141,13 @@ int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img
 int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x, int N, int G2, int d, int dt, void* stream);
 /* backward of assemble: dpatch rows copy, dcls/dpos partial sums are taken with mh_colsum */
 
+/* ---- ConvProjector (conv_projector.py:23-39): Conv2d(C->d, k3, stride s, pad 1) as an implicit GEMM -------------
+ * cols[(n,oy,ox), c*9 + ky*3 + kx] gathered from x [N*rows_per_img, C] (patch p of image n at row
+ * n*rows_per_img + row0 + p, zero padding outside the G x G grid); then mh_gemm with weight.view(d, C*9). */
+int mh_conv3x3_cols(const void* x, void* cols, int N, int G, int C, int stride, int rows_per_img, int row0, void* stream);
+/* backward of the gather: dx[N*rows_per_img, C] from dcols (deterministic gather form; non-patch rows = 0) */
+int mh_conv3x3_col2im(const void* dcols, void* dx, int N, int G, int C, int stride, int rows_per_img, int row0, int dt, void* stream);
+
 /* ---- embedding + image-feature splice (base_mmgpt.py:99-160) ------------------------------ */
 /* Builds src[b*S+s] = row index into the image-feature matrix [Nimg*P, d] if position s of
  * sample b is one of the P rows after an <im_start>, else -1 (use embed_tokens[ids]).

@@ -324,7 +324,20 @@ class HipEngine:
             if ctx is not None:
                 ctx.update(proj_in=x)
             return feats, S, (0 if cls_keep else 1), (S if cls_keep else S - 1)
-        raise NotImplementedError("ConvProjector forward on the HIP path is not implemented yet")
+        # ConvProjector (conv_projector.py:23-39): Conv2d(vd -> d, k3, stride, pad 1) over the G x G patch grid as an
+        # implicit GEMM: gather -> MFMA GEMM with weight.view(d, vd*9) in place (+bias) -> [N*(G/s)^2, d]
+        if cls_keep:
+            raise NotImplementedError("ConvProjector needs the square patch grid (vision_select_feature='patch')")
+        vd = x.shape[1]
+        G = int(round(math.sqrt(S - 1)))
+        stride = proj.conv_stride
+        cols = O.conv3x3_cols(x, N, G, vd, stride, S, 1)
+        w = A.view("model.projector.projector.weight", shape=(A.params["model.projector.projector.weight"].shape[0], vd * 9))
+        feats = O.gemm_nt(cols, w, bias=A.view("model.projector.projector.bias"))
+        Go = (G + 2 - 3) // stride + 1
+        if ctx is not None:
+            ctx.update(proj_in=cols, proj_conv=(N, G, vd, stride, S))
+        return feats, Go * Go, 0, Go * Go
 
     def projector_bwd(self, ctx, dfeats, fresh):
         """returns dx for the tower output ([N*S, vd])."""
@@ -332,6 +345,17 @@ class HipEngine:
         x = ctx["proj_in"]
         wname, bname = "model.projector.projector.weight", "model.projector.projector.bias"
         dx = None
+        if "proj_conv" in ctx:
+            N, G, vd, stride, S = ctx["proj_conv"]
+            w = A.view(wname, shape=(A.params[wname].shape[0], vd * 9))
+            if ctx["train_tower"]:
+                dcols = O.gemm_nt(dfeats, w, b_t=True)  # [rows, vd*9]
+                dx = O.conv3x3_col2im(dcols, N, G, vd, stride, S, 1)
+            if self._trainable(wname):
+                self._wgrad(dfeats, x, A.gview(wname).view(w.shape), fresh, _ru(x.shape[0], 64))
+                O.colsum(dfeats, A.gview(bname), accumulate=not fresh)
+                self._ready([wname, bname])
+            return dx
         if ctx["train_tower"]:
             dx = O.gemm_nt(dfeats, A.view(wname), b_t=True)
         if self._trainable(wname):

@@ -303,6 +303,19 @@ def vit_assemble(patch, cls, pos, N, G2):
     return x
 
 
+def conv3x3_cols(x, N, G, C, stride, rows_per_img, row0):
+    Go = (G + 2 - 3) // stride + 1
+    cols = torch.empty(N * Go * Go, C * 9, dtype=x.dtype, device=x.device)
+    L.check(L.lib().mh_conv3x3_cols(p(x), p(cols), i32(N), i32(G), i32(C), i32(stride), i32(rows_per_img), i32(row0), _stream()), "mh_conv3x3_cols")
+    return cols
+
+
+def conv3x3_col2im(dcols, N, G, C, stride, rows_per_img, row0):
+    dx = torch.empty(N * rows_per_img, C, dtype=dcols.dtype, device=dcols.device)
+    L.check(L.lib().mh_conv3x3_col2im(p(dcols), p(dx), i32(N), i32(G), i32(C), i32(stride), i32(rows_per_img), i32(row0), i32(dt_of(dcols)), _stream()), "mh_conv3x3_col2im")
+    return dx
+
+
 def splice_index(ids, img_offset, P, im_patch, im_start, im_end, err, rows_per_img=None, row0=0):
     B, S = ids.shape
     assert ids.dtype == torch.int64 and ids.is_contiguous()

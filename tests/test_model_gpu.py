@@ -39,7 +39,7 @@ def _to_dev(batch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name", ["tiny_1img", "tiny_2img", "tiny_padbatch", "tiny_textonly"])
+@pytest.mark.parametrize("name", ["tiny_1img", "tiny_2img", "tiny_padbatch", "tiny_textonly", "tiny_conv2"])
 def test_tiny_forward_backward_parity(name, dtype):
     from oracle import cases as C
     from oracle import ref_cpu as R
@@ -107,6 +107,34 @@ def test_medium_forward_parity_vs_reference_golden(dtype):
     lse = torch.logsumexp(lg, dim=-1).cpu().numpy()
     assert np.abs(lse - g["logits_lse"]).max() < 10 * tol["logits"]
     assert abs(float(out.loss) - float(g["loss"])) < tol["loss"] * abs(float(g["loss"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype):
+    """BASELINE cfg 1/2 at FULL size (24-layer ViT-L/14-336 + 32-layer Llama-7B, S=613): logits slice,
+    per-position logsumexp and loss of the HIP path vs the REAL reference's fp32 CPU outputs
+    (tests/golden/full_cfg1.npz, generated by oracle/make_golden.py full).  Tolerance at full depth (32 layers
+    of 16-bit residual stream): logits 5e-3 (fp16) / 5e-2 (bf16) of max|logit|, loss 2e-3 / 1e-2."""
+    from oracle import cases as C
+
+    path = os.path.join(GOLD, "full_cfg1.npz")
+    if not os.path.exists(path):
+        pytest.skip("full golden not generated")
+    g = np.load(path)
+    cfg, batch = C.get_case("full_cfg1")
+    assert np.array_equal(g["input_ids"], batch["input_ids"].numpy())
+    model = _build(cfg, dtype)
+    with torch.no_grad():
+        out = model(**_to_dev(batch))
+    lg = out.logits.float()
+    got = lg[:, ::16, :256].cpu().numpy()
+    tl, tloss = (5e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1e-2)
+    err = np.abs(got - g["logits_slice"]).max() / float(g["logits_absmax"])
+    assert err < tl, err
+    lse = torch.logsumexp(lg, dim=-1).cpu().numpy()
+    assert np.abs(lse - g["logits_lse"]).max() < 10 * tl
+    assert abs(float(out.loss) - float(g["loss"])) < tloss * abs(float(g["loss"])), (float(out.loss), float(g["loss"]))
+    print(f"[full cfg1 {dtype}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
 
 
 def test_medium_backward_grad_norms_vs_reference_golden():

@@ -181,6 +181,11 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
+  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided) {  // A/B arm: MFMA 32x32x16 fragments
+    g.tiles_m = (M + 255) / 256;
+    g.tiles_n = (N + 255) / 256;
+    return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
+  }
   if (big || a_kstrided || b_kstrided) {  // K-strided operands exist only in the 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;

@@ -99,5 +99,6 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& g, int m, int n, floa
 int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream);
 // operand layouts: K-contiguous (0) or K-strided (1), see gemm256.hip
 int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
+int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)
 
 }  // namespace mhgemm

@@ -122,6 +122,15 @@ int mh_attn_prep_v(const void* v, int64_t ldv, void* vt, int B, int S, int H, in
  * causal=1: Llama (D=128), causal=0: CLIP (D=64).  scale = 1/sqrt(D). */
 int mh_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, void* o, int64_t ldo,
                 float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
+/* Forward v2: identical semantics, but V is taken ROW-MAJOR (v: [B*S, H, D] view, row stride ldv) and transposed on the
+ * fly by LDS transpose-reads: no mh_attn_prep_v pass. */
+int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                 float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
+/* Backward v2: same contract as mh_attn_bwd but no workspace and no operand re-layout passes (transposed operands
+ * come from LDS transpose-reads).  `delta`: ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats. */
+int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
+                 const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                 void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
 /* Backward: `delta` is a ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats (rowsum(dO*O), then lse*log2e).
  * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
  * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */

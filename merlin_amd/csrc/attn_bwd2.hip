@@ -1,0 +1,440 @@
+// Flash attention backward v2 (gfx950): dQ, dK, dV with row-major operand tiles only.
+//
+// Same mathematics and MFMA orientations as attn_bwd.hip / attn_bwd_kv.hip (three deterministic kernels, the
+// score-like accumulator is fed straight back as the B operand of the next product), but every transposed
+// operand (K^T for dQ, dO^T for dV, Q^T for dK) is produced by LDS transpose-reads of the SAME row-major tile that
+// feeds the score product (attn_tiles.h): no mh_attn_prep_v passes, no Q^T/dO^T/K^T copies, no workspace, one
+// third less global->LDS traffic.  Tiles are 64 rows (two 32-row halves per barrier), all LDS fragment reads are
+// hand-waited inline asm in rolling windows, and the tile loop is split into branch-free full tiles and edge
+// tiles (causal diagonal / sequence end).
+//
+//   dq2  (one block per 128 queries; Q, dO fragments in registers; streams K, V tiles):
+//        S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta[q]);   dQ^T[d,q] += K^T dS^T    (K^T: transpose-read)
+//   kv2<1> dV (one block per 128 keys; K fragments in registers; streams Q, dO tiles):
+//        S = Q K^T -> P;                                               dV^T[d,kv] += dO^T P      (dO^T: transpose-read)
+//   kv2<2> dK (K, V fragments in registers):
+//        S, dP = dO V^T, dS = P o (dP - delta[q]);                     dK^T[d,kv] += Q^T dS      (Q^T: transpose-read)
+// delta[q] = rowsum(dO o O) and lse2 = lse*log2(e) come from delta2_k.  The softmax scale is applied in the epilogues.
+#include "attn_tiles.h"
+
+namespace mhattn {
+namespace {
+
+struct Bwd2Args {
+  const uint16_t *q, *k, *v, *o, *dout;
+  const float* lse;
+  float* delta;       // [2][B, H, S_pad]: delta, then lse2
+  const float* lse2;
+  uint16_t *dq, *dk, *dv;
+  const int32_t* seqlens;
+  int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int B, S, H, S_pad;
+  float scale, scale_log2;
+};
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void delta2_k(Bwd2Args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + wave;  // over B*S*H
+  if (idx >= (int64_t)a.B * a.S * a.H) return;
+  const int h = (int)(idx % a.H);
+  const int64_t t = idx / a.H;
+  const int b = (int)(t / a.S), s = (int)(t % a.S);
+  float acc;
+  if constexpr (D == 128) {
+    float x0, x1, y0, y1;
+    unpack2<DT>(*(const uint32_t*)(a.o + t * a.ldo + (int64_t)h * D + lane * 2), x0, x1);
+    unpack2<DT>(*(const uint32_t*)(a.dout + t * a.lddo + (int64_t)h * D + lane * 2), y0, y1);
+    acc = x0 * y0 + x1 * y1;
+  } else {
+    acc = ld16<DT>(a.o[t * a.ldo + (int64_t)h * D + lane]) * ld16<DT>(a.dout[t * a.lddo + (int64_t)h * D + lane]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const int64_t i = ((int64_t)b * a.H + h) * a.S_pad + s;
+    a.delta[i] = acc;
+    ((float*)a.lse2)[i] = a.lse[i] * 1.4426950408889634f;
+  }
+}
+
+// rolling-window helpers ------------------------------------------------------------------------------------
+// NF row fragments (A operands) of the 32-row half at byte offset BASE of a tile: fragment n <-> k-step n; consumer(n, frag)
+template <int BASE, int NF, int WMAX = 8, typename F>
+__device__ __forceinline__ void stream_row_frags(const unsigned* addr, F&& consume) {
+  constexpr int W = NF < WMAX ? NF : WMAX;
+  u32x4_t w[W];
+  static_for<W>([&](auto I) { constexpr int n = decltype(I)::value; lds_read128<BASE>(w[n], addr[n]); });
+  static_for<NF>([&](auto I) {
+    constexpr int n = decltype(I)::value;
+    constexpr int left = NF - 1 - n;
+    lgkm_wait<(left < W - 1 ? left : W - 1)>();
+    consume(I, w[n % W]);
+    if constexpr (n + W < NF) lds_read128<BASE>(w[n % W], addr[n + W]);
+  });
+}
+// transposed fragments of the 32-row half starting at tile row R0: fragment f = (d-block f/2, k-step f%2), NF = 2*DBLK
+template <int RB, int R0, int NF, typename F>
+__device__ __forceinline__ void stream_tr_frags(const unsigned* addr, F&& consume) {
+  u32x2_t w[8];  // window of 4 fragments
+  constexpr int W = NF < 4 ? NF : 4;
+  static_for<W>([&](auto I) {
+    constexpr int f = decltype(I)::value;
+    lds_read64_tr<(R0 + (f % 2) * 16) * RB>(w[2 * f], addr[2 * (f / 2)]);
+    lds_read64_tr<(R0 + (f % 2) * 16 + 8) * RB>(w[2 * f + 1], addr[2 * (f / 2) + 1]);
+  });
+  static_for<NF>([&](auto I) {
+    constexpr int f = decltype(I)::value;
+    constexpr int left = NF - 1 - f;
+    lgkm_wait<2 * (left < W - 1 ? left : W - 1)>();
+    const u32x4_t fr = u32x4_t{w[2 * (f % W)][0], w[2 * (f % W)][1], w[2 * (f % W) + 1][0], w[2 * (f % W) + 1][1]};
+    consume(I, fr);
+    if constexpr (f + W < NF) {
+      constexpr int g = f + W;
+      lds_read64_tr<(R0 + (g % 2) * 16) * RB>(w[2 * (f % W)], addr[2 * (g / 2)]);
+      lds_read64_tr<(R0 + (g % 2) * 16 + 8) * RB>(w[2 * (f % W) + 1], addr[2 * (g / 2) + 1]);
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ
+// ------------------------------------------------------------------------------------------------------------
+template <int DT, int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = D * 2, T_BYTES = 64 * RB, STAGE = 2 * T_BYTES;  // K, V tiles of 64 keys
+  constexpr int KSTEPS = D / 16, DBLK = D / 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nq = (a.S + 127) / 128;
+  int bh_, qi;
+  if (!xcd_work(a.B * a.H, nq, bh_, qi)) return;
+  const int qblk = CAUSAL ? nq - 1 - qi : qi;
+  const int h = bh_ % a.H, b = bh_ / a.H;
+  const int S = a.S;
+  const int len = a.seqlens ? min(a.seqlens[b], S) : S;
+  const int q0 = qblk * 128, qw0 = q0 + wave * 32, qrow = qw0 + l31;
+  uint16_t* dqp = a.dq + ((int64_t)b * S + qrow) * a.lddq + (int64_t)h * D;
+  if (q0 >= len) {
+    if (qrow < S)
+      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) *(uint2*)(dqp + d) = make_uint2(0, 0);
+    return;
+  }
+  u32x4_t qf[KSTEPS], dof[KSTEPS];
+  {
+    const int qr = min(qrow, S - 1);
+    const uint16_t* qp = a.q + ((int64_t)b * S + qr) * a.ldq + (int64_t)h * D + 8 * hi;
+    const uint16_t* dp = a.dout + ((int64_t)b * S + qr) * a.lddo + (int64_t)h * D + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      qf[ks] = *(const u32x4_t*)(qp + 16 * ks);
+      dof[ks] = *(const u32x4_t*)(dp + 16 * ks);
+    }
+  }
+  const int64_t bh = (int64_t)b * a.H + h;
+  const float lse2 = a.lse2[bh * a.S_pad + min(qrow, S - 1)];
+  const float dl = a.delta[bh * a.S_pad + min(qrow, S - 1)];
+  const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
+  const int ntiles = (kv_end + 63) / 64;
+  const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
+  const uint16_t* vbase = a.v + (int64_t)b * S * a.ldv + (int64_t)h * D;
+  auto stage = [&](int s, int kv0) {
+    char* base = smem + s * STAGE;
+    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave);
+    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave);
+  };
+  f32x16_t dqacc[DBLK];
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned off_r[KSTEPS], off_t[KSTEPS];
+  row_frag_offsets<D>(l31, hi, off_r);
+  tr_frag_offsets<D>(lane, off_t);
+  const float sc = a.scale_log2;
+
+  auto tile = [&](int j, auto EDGE_) {
+    constexpr bool EDGE = decltype(EDGE_)::value;
+    const int kv0 = j * 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < ntiles) stage((j + 1) & 1, kv0 + 64);
+    const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
+    unsigned ak[KSTEPS], av[KSTEPS], at[KSTEPS];
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) {
+      ak[i] = sb + off_r[i];
+      av[i] = sb + T_BYTES + off_r[i];
+      at[i] = sb + off_t[i];
+    }
+    static_for<2>([&](auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const int kvh = kv0 + 32 * hf;
+      if constexpr (EDGE) {
+        if ((CAUSAL && kvh > qw0 + 31) || kvh >= len) return;  // nothing visible to this wave (wave-uniform)
+      }
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      stream_row_frags<hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, qf[decltype(I)::value], sacc); });
+      stream_row_frags<hf * 32 * RB, KSTEPS>(av, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, dof[decltype(I)::value], pacc); });
+      float dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(fmaf(sacc[r], sc, -lse2));
+      if (EDGE && ((kvh + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kvh + 31 > qw0)))) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kvh + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = (kv < len) && (qrow < len) && (!CAUSAL || kv <= qrow);
+          dsv[r] = ok ? dsv[r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsv[r] *= (pacc[r] - dl);
+      const u32x4_t dsf[2] = {pack8v<DT>(dsv), pack8v<DT>(dsv + 8)};
+      stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
+        constexpr int f = decltype(I)::value;
+        dqacc[f / 2] = mfma32v<DT>(fr, dsf[f % 2], dqacc[f / 2]);
+      });
+    });
+  };
+  const int n_full = min(ntiles, (CAUSAL ? min(q0, len) : len) / 64);  // and all rows of the block < len? checked per EDGE
+  const bool rows_full = (q0 + 128 <= len);
+  stage(0, 0);
+  if (rows_full) {
+    for (int j = 0; j < n_full; ++j) tile(j, std::false_type{});
+    for (int j = n_full; j < ntiles; ++j) tile(j, std::true_type{});
+  } else {
+    for (int j = 0; j < ntiles; ++j) tile(j, std::true_type{});
+  }
+
+  if (qrow < S) {
+    const bool valid = qrow < len;
+#pragma unroll
+    for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * i + 8 * g + 4 * hi;
+        uint2 w = make_uint2(0, 0);
+        if (valid)
+          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0] * a.scale, dqacc[i][4 * g + 1] * a.scale),
+                         pack2<DT>(dqacc[i][4 * g + 2] * a.scale, dqacc[i][4 * g + 3] * a.scale));
+        *(uint2*)(dqp + d) = w;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dV (MODE 1) / dK (MODE 2)
+// ------------------------------------------------------------------------------------------------------------
+template <int DT, int D, bool CAUSAL, int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DO_DK = (MODE == 2);
+  constexpr int RB = D * 2, T_BYTES = 64 * RB;          // Q, dO tiles of 64 queries
+  constexpr int OFF_DO = T_BYTES, OFF_LSE = 2 * T_BYTES;  // + wave*512: [lse2 64 f32 | delta 64 f32]
+  constexpr int STAGE = 2 * T_BYTES + 2048;
+  constexpr int KSTEPS = D / 16, DBLK = D / 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  int bh_, kvblk;
+  if (!xcd_work(a.B * a.H, (a.S + 127) / 128, bh_, kvblk)) return;
+  const int h = bh_ % a.H, b = bh_ / a.H;
+  const int S = a.S;
+  const int len = a.seqlens ? min(a.seqlens[b], S) : S;
+  const int kv0 = kvblk * 128, kvw0 = kv0 + wave * 32, kvrow = kvw0 + l31;
+  uint16_t* outp = (DO_DK ? a.dk + ((int64_t)b * S + kvrow) * a.lddk : a.dv + ((int64_t)b * S + kvrow) * a.lddv) + (int64_t)h * D;
+  if (kv0 >= len) {
+    if (kvrow < S)
+      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) *(uint2*)(outp + d) = make_uint2(0, 0);
+    return;
+  }
+  // K (and V) fragments of this wave's 32 keys: B operands
+  u32x4_t kf[KSTEPS], vf[DO_DK ? KSTEPS : 1];
+  {
+    const int kr = min(kvrow, S - 1);
+    const uint16_t* kp = a.k + ((int64_t)b * S + kr) * a.ldk + (int64_t)h * D + 8 * hi;
+    const uint16_t* vp = a.v + ((int64_t)b * S + kr) * a.ldv + (int64_t)h * D + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      kf[ks] = *(const u32x4_t*)(kp + 16 * ks);
+      if constexpr (DO_DK) vf[ks] = *(const u32x4_t*)(vp + 16 * ks);
+    }
+  }
+  const int q_begin = CAUSAL ? kv0 : 0;
+  const int ntiles = (len - q_begin + 63) / 64;
+  const uint16_t* qbase = a.q + (int64_t)b * S * a.ldq + (int64_t)h * D;
+  const uint16_t* dobase = a.dout + (int64_t)b * S * a.lddo + (int64_t)h * D;
+  const float* lse_row = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
+  const float* dl_row = a.delta + ((int64_t)b * a.H + h) * a.S_pad;
+  auto stage = [&](int s, int q0) {
+    char* base = smem + s * STAGE;
+    stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave);
+    stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave);
+    // per-wave copy: lanes 0-63 -> lse2[q0 + lane], then delta[q0 + lane] (2 x 256 contiguous LDS bytes)
+    glds4(lse_row + q0 + lane, base + OFF_LSE + wave * 512);
+    glds4(dl_row + q0 + lane, base + OFF_LSE + wave * 512 + 256);
+  };
+  f32x16_t acc[DBLK];
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned off_r[KSTEPS], off_t[KSTEPS];
+  row_frag_offsets<D>(l31, hi, off_r);
+  tr_frag_offsets<D>(lane, off_t);
+  const unsigned off_l = OFF_LSE + wave * 512 + hi * 16;
+  const float sc = a.scale_log2;
+
+  auto tile = [&](int j, auto EDGE_) {
+    constexpr bool EDGE = decltype(EDGE_)::value;
+    const int q0 = q_begin + j * 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < ntiles) stage((j + 1) & 1, q0 + 64);
+    const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
+    unsigned aq[KSTEPS], ado[KSTEPS], at[KSTEPS];
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) {
+      aq[i] = sb + off_r[i];
+      ado[i] = sb + OFF_DO + off_r[i];
+      at[i] = sb + (DO_DK ? 0 : OFF_DO) + off_t[i];  // dK: Q^T from the Q tile; dV: dO^T from the dO tile
+    }
+    const unsigned al = sb + off_l;
+    static_for<2>([&](auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const int qh = q0 + 32 * hf;
+      if constexpr (EDGE) {
+        if ((CAUSAL && kvw0 > qh + 31) || qh >= len) return;  // this wave's keys see none of these queries
+      }
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      stream_row_frags<hf * 32 * RB, KSTEPS>(aq, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, kf[decltype(I)::value], sacc); });
+      // lse2 / delta of the 16 query rows this lane's registers stand for: q = qh + 8*g + 4*hi + e.  Issued here so
+      // that (dK) their latency hides under the dP products while they are not live during the S products.
+      u32x4_t lsev[4], dlv[DO_DK ? 4 : 1];
+      static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<hf * 128 + 32 * g>(lsev[g], al); });
+      if constexpr (DO_DK) {
+        static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<256 + hf * 128 + 32 * g>(dlv[g], al); });
+        stream_row_frags<hf * 32 * RB, KSTEPS, 4>(ado, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, vf[decltype(I)::value], pacc); });
+      } else {
+        lgkm_wait<0>();
+      }
+      float pv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(sacc[4 * g + e], sc, -__uint_as_float(lsev[g][e])));
+      if (EDGE && ((qh + 32 > len) || (kvw0 + 32 > len) || (CAUSAL && (kvw0 + 31 > qh)))) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = qh + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = (q < len) && (kvrow < len) && (!CAUSAL || kvrow <= q);
+          pv[r] = ok ? pv[r] : 0.f;
+        }
+      }
+      if constexpr (DO_DK) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[4 * g + e] *= (pacc[4 * g + e] - __uint_as_float(dlv[g][e]));  // dS (unscaled)
+      }
+      const u32x4_t pf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
+      stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
+        constexpr int f = decltype(I)::value;
+        acc[f / 2] = mfma32v<DT>(fr, pf[f % 2], acc[f / 2]);
+      });
+    });
+  };
+  // tiles: diagonal tiles first (j < n_diag), then fully visible ones, then the tail at the sequence end
+  const bool keys_full = (kv0 + 128 <= len);
+  const int n_diag = CAUSAL ? min(ntiles, 2) : 0;                     // q0 in {kv0, kv0+64}: touches the diagonal
+  const int n_tail = (len % 64) ? 1 : 0;                               // last tile crosses `len`
+  const int j_full_end = keys_full ? max(n_diag, ntiles - n_tail) : n_diag;
+  stage(0, q_begin);
+  for (int j = 0; j < n_diag; ++j) tile(j, std::true_type{});
+  for (int j = n_diag; j < j_full_end; ++j) tile(j, std::false_type{});
+  for (int j = max(n_diag, j_full_end); j < ntiles; ++j) tile(j, std::true_type{});
+
+  if (kvrow < S) {
+    const bool valid = kvrow < len;
+    const float osc = DO_DK ? a.scale : 1.0f;
+#pragma unroll
+    for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * i + 8 * g + 4 * hi;
+        uint2 w = make_uint2(0, 0);
+        if (valid)
+          w = make_uint2(pack2<DT>(acc[i][4 * g + 0] * osc, acc[i][4 * g + 1] * osc), pack2<DT>(acc[i][4 * g + 2] * osc, acc[i][4 * g + 3] * osc));
+        *(uint2*)(outp + d) = w;
+      }
+  }
+}
+
+template <int DT, int D, bool CAUSAL>
+int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
+  constexpr size_t ldsQ = 2 * 2 * 64 * D * 2, ldsKV = 2 * (2 * 64 * D * 2 + 2048);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_bwd2_dq_k<DT, D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsQ);
+    hipFuncSetAttribute((const void*)attn_bwd2_kv_k<DT, D, CAUSAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsKV);
+    hipFuncSetAttribute((const void*)attn_bwd2_kv_k<DT, D, CAUSAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsKV);
+    attr = true;
+  }
+  const int64_t nth = (int64_t)a.B * a.S * a.H;
+  hipLaunchKernelGGL((delta2_k<DT, D>), dim3((unsigned)((nth + 3) / 4)), dim3(256), 0, st, a);
+  dim3 grid(xcd_grid(a.B * a.H, (a.S + 127) / 128));
+  hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 1>), grid, dim3(256), ldsKV, st, a);
+  hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 2>), grid, dim3(256), ldsKV, st, a);
+  hipLaunchKernelGGL((attn_bwd2_dq_k<DT, D, CAUSAL>), grid, dim3(256), ldsQ, st, a);
+  MH_LAUNCH_CHECK();
+}
+
+}  // namespace
+}  // namespace mhattn
+
+extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                            int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq,
+                            void* dk, int64_t lddk, void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D,
+                            int causal, int dt, void* stream) {
+  using namespace mhattn;
+  if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return MH_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 1) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
+  if (D != 128 && D != 64) return MH_ERR_SHAPE;
+  Bwd2Args a;
+  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o;
+  a.dout = (const uint16_t*)dout; a.lse = lse; a.delta = delta;
+  a.B = B; a.S = S; a.H = H; a.S_pad = (S + 63) / 64 * 64;
+  a.lse2 = delta + (int64_t)B * H * a.S_pad;
+  a.dq = (uint16_t*)dq; a.dk = (uint16_t*)dk; a.dv = (uint16_t*)dv; a.seqlens = seqlens;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.scale = 1.0f / sqrtf((float)D);
+  a.scale_log2 = a.scale * 1.4426950408889634f;
+  hipStream_t st = as_stream(stream);
+#define GO(DT_, D_, C_) return launch_bwd2<DT_, D_, C_>(a, st)
+  if (dt == MH_BF16) {
+    if (D == 128) { if (causal) GO(MH_BF16, 128, true); else GO(MH_BF16, 128, false); }
+    else { if (causal) GO(MH_BF16, 64, true); else GO(MH_BF16, 64, false); }
+  } else if (dt == MH_F16) {
+    if (D == 128) { if (causal) GO(MH_F16, 128, true); else GO(MH_F16, 128, false); }
+    else { if (causal) GO(MH_F16, 64, true); else GO(MH_F16, 64, false); }
+  }
+#undef GO
+  return MH_ERR_DTYPE;
+}

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_m32.hip", "norm.hip", "elementwise.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_bwd_kv.hip", "loss_splice.hip", "conv.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_m32.hip", "norm.hip", "elementwise.hip", "attn_fwd.hip", "attn_fwd2.hip", "attn_bwd.hip", "attn_bwd_kv.hip", "attn_bwd2.hip", "loss_splice.hip", "conv.hip"]
 LIB = os.path.join(HERE, "libmerlin_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -27,7 +27,7 @@ def _hipcc():
 def _newer(src, dst):
     if not os.path.exists(dst):
         return True
-    deps = [src, os.path.join(HERE, "mh_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "attn_bwd_common.h"), os.path.join(HERE, "..", "..", "include", "merlin_hip.h")]
+    deps = [src, os.path.join(HERE, "mh_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "attn_bwd_common.h"), os.path.join(HERE, "attn_tiles.h"), os.path.join(HERE, "..", "..", "include", "merlin_hip.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(dst) for d in deps)
 
 

@@ -186,8 +186,7 @@ class HipEngine:
         h1 = O.layernorm_fwd(x, W.ln1w, W.ln1b, eps)
         qkv = O.gemm_nt(h1, W.wqkv, bias=W.bqkv)
         q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
-        vt = O.attn_prep_v(v, N, S, H, D)
-        o, lse = O.attn_fwd(q, k, vt, N, S, H, D, causal=False)
+        o, lse = O.attn_fwd2(q, k, v, N, S, H, D, causal=False)
         x2 = O.gemm_nt(o, W.wo, bias=W.bo, resid=x)
         h2 = O.layernorm_fwd(x2, W.ln2w, W.ln2b, eps)
         if keep:
@@ -227,7 +226,7 @@ class HipEngine:
         O.colsum(dx2, A.gview(p + "self_attn.out_proj.bias"), accumulate=acc)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
-        O.attn_bwd(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
+        O.attn_bwd2(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd)), fresh, Tpad)
         O.colsum(dqkv, A.gspan(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,)), accumulate=acc)
@@ -376,8 +375,7 @@ class HipEngine:
         qkv = O.gemm_nt(h1, W.wqkv)
         O.rope_qk_(qkv, self.rope, S, H, D)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        vt = O.attn_prep_v(v, B, S, H, D)
-        o, lse = O.attn_fwd(q, k, vt, B, S, H, D, causal=True, seqlens=lens)
+        o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         x2 = O.gemm_nt(o, W.wo, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
         gu = O.gemm_nt(h2, W.wgu)
@@ -415,7 +413,7 @@ class HipEngine:
             self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        O.attn_bwd(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
+        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
         O.rope_qk_(dqkv, self.rope, S, H, D, inverse=True)
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:

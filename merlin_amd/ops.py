@@ -274,6 +274,28 @@ def attn_fwd(q, k, vt, B, S, H, D, causal, seqlens=None, out=None, lse=None):
     return out, lse
 
 
+def attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=None, out=None, lse=None):
+    """q, k, v: [B*S, H*D] views (own row strides).  Returns (o [B*S, H*D], lse [B,H,S_pad]).  No V re-layout pass."""
+    out = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if out is None else out
+    lse = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device) if lse is None else lse
+    L.check(L.lib().mh_attn_fwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(out), i64(out.stride(0)),
+                                 p(lse), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), i32(dt_of(q)), _stream()), "mh_attn_fwd2")
+    return out, lse
+
+
+def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None):
+    """Backward without re-layout passes or workspace (transpose-read kernels)."""
+    dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
+    dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
+    dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
+    delta = torch.zeros(2, B, H, round_up(S, 64), dtype=torch.float32, device=q.device)  # [delta | lse*log2e]
+    L.check(L.lib().mh_attn_bwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
+                                 p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
+                                 p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)),
+                                 i32(dt_of(q)), _stream()), "mh_attn_bwd2")
+    return dq, dk, dv
+
+
 def attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None):
     dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk

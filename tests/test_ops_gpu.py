@@ -249,6 +249,9 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     q32, k32, v32 = (t.float().reshape(B, S, H, D).clone().requires_grad_() for t in (q, k, v))
     ref = _attn_ref(q32, k32, v32, causal, lens_t.long())
     assert relerr(o.view(B, S, H, D), ref) < 4 * EPS16[dtype], "forward"
+    o2, lse2 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens_t if lens else None)  # transpose-read V path
+    assert relerr(o2.view(B, S, H, D), ref) < 4 * EPS16[dtype], "forward v2"
+    assert float((lse2 - lse).abs().max()) < 1e-3
     # lse check on valid rows
     sc = (q32.permute(0, 2, 1, 3) @ k32.permute(0, 2, 3, 1)) / math.sqrt(D)
     ar = torch.arange(S, device=dev())
@@ -267,6 +270,10 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     assert relerr(dv.view(B, S, H, D), v32.grad) < tol, "dv"
     assert relerr(dk.view(B, S, H, D), k32.grad) < tol, "dk"
     assert relerr(dq.view(B, S, H, D), q32.grad) < tol, "dq"
+    dq2, dk2, dv2 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    assert relerr(dv2.view(B, S, H, D), v32.grad) < tol, "dv (v2)"
+    assert relerr(dk2.view(B, S, H, D), k32.grad) < tol, "dk (v2)"
+    assert relerr(dq2.view(B, S, H, D), q32.grad) < tol, "dq (v2)"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

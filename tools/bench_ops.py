@@ -39,9 +39,15 @@ def bench_attn(B, S, H, D, causal):
     t = timeit(lambda: O.attn_fwd(q, k, vt, B, S, H, D, causal, out=o, lse=lse))
     fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
     print(f"attn_fwd B={B} S={S} H={H} D={D} causal={causal}: {t*1e3:.3f} ms  {fl/t/1e12:.0f} TFLOP/s", flush=True)
+    if hasattr(O, "attn_fwd2"):
+        t_ = timeit(lambda: O.attn_fwd2(q, k, v, B, S, H, D, causal, out=o, lse=lse))
+        print(f"attn_fwd2 (no prep_v): {t_*1e3:.3f} ms  {fl/t_/1e12:.0f} TFLOP/s", flush=True)
     do = torch.randn(B * S, H * D, device=dev).to(dtype)
     t2 = timeit(lambda: O.attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal), iters=5, warm=2)
     print(f"attn_bwd: {t2*1e3:.3f} ms  {2.5*fl/t2/1e12:.0f} TFLOP/s (5 matmuls counted)", flush=True)
+    if hasattr(O, "attn_bwd2"):
+        t_ = timeit(lambda: O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal), iters=5, warm=2)
+        print(f"attn_bwd2 (no re-layout passes): {t_*1e3:.3f} ms  {2.5*fl/t_/1e12:.0f} TFLOP/s", flush=True)
     t3 = timeit(lambda: O.attn_prep_v(v, B, S, H, D, out=vt))
     print(f"prep_v: {t3*1e3:.3f} ms  {2*B*S*H*D*2/t3/1e9:.0f} GB/s", flush=True)
 

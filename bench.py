@@ -94,6 +94,9 @@ def main():
                     "gradient checkpointing) instead of keeping activations resident in the 288 GB of HBM")
     ap.add_argument("--fwd-only", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("MH_GEMM_FORCE"):  # A/B arm selection for kernel development (see mh_gemm_force_kernel)
+        from merlin_amd import ops as _O
+        _O.gemm_force_kernel(int(os.environ["MH_GEMM_FORCE"]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

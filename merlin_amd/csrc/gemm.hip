@@ -110,15 +110,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmArgs g) {
   }
 
   // lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3
+  epi_dispatch<DT>(g, [&](auto store) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-      epi_store4<DT>(g, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        store(m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
     }
-  }
+  });
 }
 
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
   }
 }
 
-int g_force_kernel = 0;  // 0 auto, 128, 256 (tests / A-B benchmarking)
+int g_force_kernel = 0;  // 0 auto, 128, 256 (8 waves), 4 (4 waves), 5.. (timing probes) - tests / A-B benchmarking
 
 }  // namespace
 
@@ -186,7 +188,12 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (big || a_kstrided || b_kstrided) {  // K-strided operands exist only in the 256-tile kernel
+  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
+    g.tiles_m = (M + 255) / 256;
+    g.tiles_n = (N + 255) / 256;
+    return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
+  }
+  if (big || a_kstrided || b_kstrided) {  // K-strided operands exist only in the 8-wave 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_256(g, dt, a_kstrided, b_kstrided, as_stream(stream));

@@ -33,6 +33,8 @@
 // supplies the address of row i>>2, columns 4*(i&3)..+3 of a 4x16 block and receives column i).  Swizzle: the
 // 32-byte column chunk is XORed with f(k) = (k&3) | ((k>>3)&1)<<2, which is a per-lane constant for the tr
 // read pattern and makes both 32-lane halves of every ds_read_b64_tr_b16 hit 8 distinct 32-B slots.
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace mhgemm {
@@ -51,6 +53,8 @@ __device__ __forceinline__ f32x4_t mfma16v(u32x4 a, u32x4 b, f32x4_t c) {
 constexpr int HALF_BYTES = 128 * BK * 2;  // 16 KiB: 128 rows x 64 k
 constexpr int STAGE256 = 4 * HALF_BYTES;  // A0 A1 B0 B1
 constexpr int H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3;
+constexpr int C_ROW = 528;                 // C staging row: 256 x 16-bit + 16 B pad
+constexpr int LDS256 = 256 * C_ROW;        // >= 2 * STAGE256: two stages during the loop, the C tile after it
 
 #define MH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define MH_BAR()                         \
@@ -239,20 +243,68 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
   if (wm == 0) MH_BAR();
   MH_WAIT_VM(0);  // drain the (redundant) tail loads before the block's LDS is released
 
+  // Staged epilogue (16-bit C, vectorisable layout): the accumulator layout gives a lane 4 consecutive n of one
+  // row, i.e. 32-byte pieces of 16 different rows per store instruction (measured: several microseconds per
+  // tile).  The block instead packs the whole 256x256 tile into LDS ([256 rows][528 B]: 512 B of data + 16 B pad;
+  // conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 512
+  // contiguous bytes per row.
+  if (epi_can_stage(g)) {
+    __syncthreads();  // every wave is done with the operand tiles in LDS
+    const unsigned st_w = lds0 + (unsigned)(wm * 64 + (lane & 15)) * C_ROW + (unsigned)(wn * 32 + 4 * (lane >> 4)) * 2;
+    auto fill = [&](auto EPI_) {
+      constexpr int EPI = decltype(EPI_)::value;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + a * 128 + wm * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < 4; ++i) {
+          const int m = min(m0 + a * 128 + wm * 64 + i * 16 + (lane & 15), g.M - 1);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
-          const f32x4_t v = acc[a][i][b][j];
-          epi_store4<DT>(g, m, n, v[0], v[1], v[2], v[3]);
+            for (int j = 0; j < 2; ++j) {
+              const int n = min(n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4), g.N - 4);
+              float v[4] = {acc[a][i][b][j][0], acc[a][i][b][j][1], acc[a][i][b][j][2], acc[a][i][b][j][3]};
+              epi_xform4<DT, EPI>(g, m, n, v);
+              const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+              *(uint2*)(smem + (st_w - lds0) + (a * 128 + i * 16) * C_ROW + (b * 128 + j * 16) * 2) = pk;
+            }
         }
+    };
+    switch (g.epi) {
+      case 0: fill(std::integral_constant<int, 0>{}); break;
+      case MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_RESIDUAL>{}); break;
+      case MH_EPI_BIAS: fill(std::integral_constant<int, MH_EPI_BIAS>{}); break;
+      case MH_EPI_BIAS | MH_EPI_QUICK_GELU: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{}); break;
+      case MH_EPI_BIAS | MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_RESIDUAL>{}); break;
+      default: break;  // excluded by epi_can_stage
     }
+    __syncthreads();
+    const int ncol = n0 + (tid & 31) * 8;
+    const bool n_ok = ncol < g.N;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 16 + (tid >> 5);
+      const uint4 v = *(const uint4*)(smem + row * C_ROW + (tid & 31) * 16);
+      if (n_ok && m0 + row < g.M) *(uint4*)((uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc + ncol) = v;
+    }
+    return;
+  }
+  epi_dispatch<DT>(g, [&](auto store) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + a * 128 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
+            const f32x4_t v = acc[a][i][b][j];
+            store(m, n, v[0], v[1], v[2], v[3]);
+          }
+      }
+  });
 }
 
 }  // namespace
@@ -261,10 +313,10 @@ template <int DT, bool AKS, bool BKS>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_256<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE256);
+    hipFuncSetAttribute((const void*)gemm_nt_256<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(512), 2 * STAGE256, stream, g);
+  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS256, stream, g);
   MH_LAUNCH_CHECK();
 }
 

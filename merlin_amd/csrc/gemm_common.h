@@ -95,10 +95,117 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& g, int m, int n, floa
   }
 }
 
+// Compile-time epilogue: the flag tests of epi_store4 cost ~100 instructions per call when `epi` is a run-time
+// value, i.e. ~50 k cycles for the 64 calls of a 128x128 wave quadrant - as much as 25 K-steps of MFMA work.  The
+// kernels therefore branch ONCE on g.epi (epi_dispatch) into a store loop specialised for the common flag sets
+// (vectorisable layouts only); everything else goes through the generic epi_store4.
+template <int DT, int EPI>
+struct EpiStoreFast {
+  const GemmArgs& g;
+  __device__ __forceinline__ void operator()(int m, int n, float v0, float v1, float v2, float v3) const {
+    if (m >= g.M || n >= g.N) return;
+    float v[4] = {v0, v1, v2, v3};
+    if constexpr (EPI & MH_EPI_BIAS) {
+      const uint2 bb = *(const uint2*)(g.bias + n);
+      float b0, b1, b2, b3;
+      unpack2<DT>(bb.x, b0, b1);
+      unpack2<DT>(bb.y, b2, b3);
+      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+    }
+    if constexpr (EPI & MH_EPI_QUICK_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    }
+    if constexpr (EPI & MH_EPI_RESIDUAL) {
+      const uint2 rr = *(const uint2*)(g.resid + (int64_t)m * g.ldr + n);
+      float r0, r1, r2, r3;
+      unpack2<DT>(rr.x, r0, r1);
+      unpack2<DT>(rr.y, r2, r3);
+      v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+    }
+    if constexpr (EPI & MH_EPI_OUT_F32) {
+      float4* dst = (float4*)((float*)g.C + (int64_t)m * g.ldc + n);
+      if constexpr (EPI & MH_EPI_ACCUM) {
+        const float4 o = *dst;
+        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+      }
+      *dst = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      uint2* dst = (uint2*)((uint16_t*)g.C + (int64_t)m * g.ldc + n);
+      if constexpr (EPI & MH_EPI_ACCUM) {
+        const uint2 o = *dst;
+        float o0, o1, o2, o3;
+        unpack2<DT>(o.x, o0, o1);
+        unpack2<DT>(o.y, o2, o3);
+        v[0] += o0; v[1] += o1; v[2] += o2; v[3] += o3;
+      }
+      *dst = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+    }
+  }
+};
+// The value transform alone (bias / quick-GELU / residual in fp32), for epilogues that stage the 16-bit result
+// through LDS to get full-line global stores.  Requires the vectorisable layout (g.vec_ok) and m < M, n + 3 < N.
+template <int DT, int EPI>
+__device__ __forceinline__ void epi_xform4(const GemmArgs& g, int m, int n, float (&v)[4]) {
+  if constexpr (EPI & MH_EPI_BIAS) {
+    const uint2 bb = *(const uint2*)(g.bias + n);
+    float b0, b1, b2, b3;
+    unpack2<DT>(bb.x, b0, b1);
+    unpack2<DT>(bb.y, b2, b3);
+    v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+  }
+  if constexpr (EPI & MH_EPI_QUICK_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+  }
+  if constexpr (EPI & MH_EPI_RESIDUAL) {
+    const uint2 rr = *(const uint2*)(g.resid + (int64_t)m * g.ldr + n);
+    float r0, r1, r2, r3;
+    unpack2<DT>(rr.x, r0, r1);
+    unpack2<DT>(rr.y, r2, r3);
+    v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+  }
+}
+// true when the 16-bit result can be written as 16-byte row segments (staged epilogues)
+__device__ __forceinline__ bool epi_can_stage(const GemmArgs& g) {
+  const int e = g.epi;
+  const bool known = e == 0 || e == MH_EPI_RESIDUAL || e == MH_EPI_BIAS || e == (MH_EPI_BIAS | MH_EPI_QUICK_GELU) ||
+                     e == (MH_EPI_BIAS | MH_EPI_RESIDUAL);
+  return known && g.vec_ok && (g.N % 8 == 0) && (g.ldc % 8 == 0) && ((((uintptr_t)g.C) & 15u) == 0);
+}
+
+// (inlined: an out-of-line call would give the kernels a scratch segment, which costs far more at wave launch)
+template <int DT>
+struct EpiStoreGeneric {
+  const GemmArgs& g;
+  __device__ __forceinline__ void operator()(int m, int n, float v0, float v1, float v2, float v3) const {
+    epi_store4<DT>(g, m, n, v0, v1, v2, v3);
+  }
+};
+// body(store): the kernel's loop over its accumulator tiles, calling store(m, n, v0, v1, v2, v3)
+template <int DT, typename F>
+__device__ __forceinline__ void epi_dispatch(const GemmArgs& g, F&& body) {
+  if (g.vec_ok) {
+    switch (g.epi) {
+      case 0: body(EpiStoreFast<DT, 0>{g}); return;
+      case MH_EPI_RESIDUAL: body(EpiStoreFast<DT, MH_EPI_RESIDUAL>{g}); return;
+      case MH_EPI_BIAS: body(EpiStoreFast<DT, MH_EPI_BIAS>{g}); return;
+      case MH_EPI_BIAS | MH_EPI_QUICK_GELU: body(EpiStoreFast<DT, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{g}); return;
+      case MH_EPI_BIAS | MH_EPI_RESIDUAL: body(EpiStoreFast<DT, MH_EPI_BIAS | MH_EPI_RESIDUAL>{g}); return;
+      case MH_EPI_OUT_F32: body(EpiStoreFast<DT, MH_EPI_OUT_F32>{g}); return;
+      case MH_EPI_OUT_F32 | MH_EPI_ACCUM: body(EpiStoreFast<DT, MH_EPI_OUT_F32 | MH_EPI_ACCUM>{g}); return;
+      case MH_EPI_ACCUM: body(EpiStoreFast<DT, MH_EPI_ACCUM>{g}); return;
+      default: break;
+    }
+  }
+  body(EpiStoreGeneric<DT>{g});
+}
+
 // defined in gemm256.hip
 int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream);
 // operand layouts: K-contiguous (0) or K-strided (1), see gemm256.hip
 int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
+int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0);      // gemm256w4.hip (4 waves x 128x128)
 int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)
 
 }  // namespace mhgemm

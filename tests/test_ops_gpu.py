@@ -398,14 +398,16 @@ def test_gemm_kstrided_operands(ops, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1000, 515, 256), (613, 4096, 1024),
                                    (2048, 2048, 4096), (300, 103, 64), (4096, 11008, 512)])
-def test_gemm_256_tile_kernel(ops, dtype, M, N, K):
-    """The pipelined 256x256 kernel (forced), incl. M/N edges, short K (prologue/tail clamps) and epilogues;
-    repeated to catch pipeline races (results must be bit-identical run to run)."""
+@pytest.mark.parametrize("which", [256, 4])
+def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
+    """The pipelined 256x256 kernels (forced: 256 = 8 waves, 4 = 4 waves x 128x128 with AGPR accumulators), incl.
+    M/N edges, short K (prologue/tail clamps) and epilogues (direct and LDS-staged); repeated to catch pipeline
+    races (results must be bit-identical run to run)."""
     a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
     bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
     ref = a.float() @ b.float().t()
     try:
-        ops.gemm_force_kernel(256)
+        ops.gemm_force_kernel(which)
         out = ops.gemm_nt(a, b)
         assert relerr(out, ref) < 3 * EPS16[dtype]
         for _ in range(3):
@@ -415,6 +417,11 @@ def test_gemm_256_tile_kernel(ops, dtype, M, N, K):
         if N % 4 == 0:
             z = ops.gemm_nt(a, b, bias=bias, resid=resid)
             assert relerr(z, ref + bias.float() + resid.float()) < 4 * EPS16[dtype]
+            z = ops.gemm_nt(a, b, resid=resid)
+            assert relerr(z, ref + resid.float()) < 4 * EPS16[dtype]
+            z = ops.gemm_nt(a, b, bias=bias, act="quick_gelu")
+            y = ref + bias.float()
+            assert relerr(z, y * torch.sigmoid(1.702 * y)) < 4 * EPS16[dtype]
         ops.gemm_force_kernel(128)
         assert torch.equal(ops.gemm_nt(a, b, out_f32=True), o32) or relerr(ops.gemm_nt(a, b, out_f32=True), o32) < 1e-5
     finally:

@@ -14,7 +14,9 @@
 //        S = Q K^T -> P;                                               dV^T[d,kv] += dO^T P      (dO^T: transpose-read)
 //   kv2<2> dK (K, V fragments in registers):
 //        S, dP = dO V^T, dS = P o (dP - delta[q]);                     dK^T[d,kv] += Q^T dS      (Q^T: transpose-read)
-// delta[q] = rowsum(dO o O) and lse2 = lse*log2(e) come from delta2_k.  The softmax scale is applied in the epilogues.
+// delta2_k writes -delta[q] = -rowsum(dO o O) and -lse[q]/scale: the score and dP accumulators START from them, so
+// P = exp2(scale*log2e * acc_S) and dS = P o acc_dP need no per-element subtraction and (dK) no registers to hold
+// lse/delta next to the accumulators.  The softmax scale of dQ/dK is applied in the epilogues.
 #include "attn_tiles.h"
 
 namespace mhattn {
@@ -23,13 +25,13 @@ namespace {
 struct Bwd2Args {
   const uint16_t *q, *k, *v, *o, *dout;
   const float* lse;
-  float* delta;       // [2][B, H, S_pad]: delta, then lse2
+  float* delta;       // [2][B, H, S_pad]: -delta, then lse2 = -lse/scale (both are accumulator INITIAL values)
   const float* lse2;
   uint16_t *dq, *dk, *dv;
   const int32_t* seqlens;
   int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int B, S, H, S_pad;
-  float scale, scale_log2;
+  float scale, scale_log2, inv_scale;
 };
 
 template <int N>
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void delta2_k(Bwd2Args a) {
   acc = wave_sum(acc);
   if (lane == 0) {
     const int64_t i = ((int64_t)b * a.H + h) * a.S_pad + s;
-    a.delta[i] = acc;
-    ((float*)a.lse2)[i] = a.lse[i] * 1.4426950408889634f;
+    a.delta[i] = -acc;
+    ((float*)a.lse2)[i] = -a.lse[i] * a.inv_scale;
   }
 }
 
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
     }
   }
   const int64_t bh = (int64_t)b * a.H + h;
-  const float lse2 = a.lse2[bh * a.S_pad + min(qrow, S - 1)];
-  const float dl = a.delta[bh * a.S_pad + min(qrow, S - 1)];
+  const float nls = a.lse2[bh * a.S_pad + min(qrow, S - 1)];   // -lse/scale
+  const float ndl = a.delta[bh * a.S_pad + min(qrow, S - 1)];  // -delta
   const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
   const int ntiles = (kv_end + 63) / 64;
   const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
@@ -184,13 +186,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
         if ((CAUSAL && kvh > qw0 + 31) || kvh >= len) return;  // nothing visible to this wave (wave-uniform)
       }
       f32x16_t sacc, pacc;
+      float nl_ = nls, nd_ = ndl;
+      asm volatile("" : "+v"(nl_), "+v"(nd_));  // opaque: keeps hipcc from hoisting 32 registers of splatted initial values out of the loop
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { sacc[r] = nl_; pacc[r] = nd_; }
       stream_row_frags<hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, qf[decltype(I)::value], sacc); });
       stream_row_frags<hf * 32 * RB, KSTEPS>(av, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, dof[decltype(I)::value], pacc); });
       float dsv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(fmaf(sacc[r], sc, -lse2));
+      for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(sacc[r] * sc);
       if (EDGE && ((kvh + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kvh + 31 > qw0)))) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsv[r] *= (pacc[r] - dl);
+      for (int r = 0; r < 16; ++r) dsv[r] *= pacc[r];
       const u32x4_t dsf[2] = {pack8v<DT>(dsv), pack8v<DT>(dsv + 8)};
       stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
         constexpr int f = decltype(I)::value;
@@ -321,25 +325,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
       if constexpr (EDGE) {
         if ((CAUSAL && kvw0 > qh + 31) || qh >= len) return;  // this wave's keys see none of these queries
       }
+      // -lse/scale and -delta of the 16 query rows this lane's accumulator registers stand for (q = qh + 8*g + 4*hi
+      // + e) are read straight into the accumulators: issued ahead of the fragment stream (LDS returns in order, so the
+      // stream's first wait covers them) and moved in just before the first MFMA.
       f32x16_t sacc, pacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-      stream_row_frags<hf * 32 * RB, KSTEPS>(aq, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, kf[decltype(I)::value], sacc); });
-      // lse2 / delta of the 16 query rows this lane's registers stand for: q = qh + 8*g + 4*hi + e.  Issued here so
-      // that (dK) their latency hides under the dP products while they are not live during the S products.
-      u32x4_t lsev[4], dlv[DO_DK ? 4 : 1];
+      u32x4_t lsev[4];
       static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<hf * 128 + 32 * g>(lsev[g], al); });
+      stream_row_frags<hf * 32 * RB, KSTEPS>(aq, [&](auto I, const u32x4_t& fr) {
+        if constexpr (decltype(I)::value == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc[4 * g + e] = __uint_as_float(lsev[g][e]);
+        }
+        sacc = mfma32v<DT>(fr, kf[decltype(I)::value], sacc);
+      });
       if constexpr (DO_DK) {
+        u32x4_t dlv[4];
         static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<256 + hf * 128 + 32 * g>(dlv[g], al); });
-        stream_row_frags<hf * 32 * RB, KSTEPS, 4>(ado, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, vf[decltype(I)::value], pacc); });
-      } else {
-        lgkm_wait<0>();
+        stream_row_frags<hf * 32 * RB, KSTEPS, 4>(ado, [&](auto I, const u32x4_t& fr) {
+          if constexpr (decltype(I)::value == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pacc[4 * g + e] = __uint_as_float(dlv[g][e]);
+          }
+          pacc = mfma32v<DT>(fr, vf[decltype(I)::value], pacc);
+        });
       }
       float pv[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(sacc[4 * g + e], sc, -__uint_as_float(lsev[g][e])));
+      for (int r = 0; r < 16; ++r) pv[r] = fast_exp2(sacc[r] * sc);
       if (EDGE && ((qh + 32 > len) || (kvw0 + 32 > len) || (CAUSAL && (kvw0 + 31 > qh)))) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -350,9 +366,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
       }
       if constexpr (DO_DK) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pv[4 * g + e] *= (pacc[4 * g + e] - __uint_as_float(dlv[g][e]));  // dS (unscaled)
+        for (int r = 0; r < 16; ++r) pv[r] *= pacc[r];  // dS (unscaled)
       }
       const u32x4_t pf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
       stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
@@ -426,6 +440,7 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2 = a.scale * 1.4426950408889634f;
+  a.inv_scale = sqrtf((float)D);
   hipStream_t st = as_stream(stream);
 #define GO(DT_, D_, C_) return launch_bwd2<DT_, D_, C_>(a, st)
   if (dt == MH_BF16) {

@@ -195,19 +195,30 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ partial, int nblk, int d,
-                                                         void* __restrict__ out, int out_dt, int accumulate) {
-  // 64 columns per block; the 4 waves split the partial rows 4 ways (fixed order: deterministic)
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (e < d)
-    for (int b = g; b < nblk; b += 4) s += partial[(int64_t)b * d + e];
-  red[g][lane] = s;
+__global__ __launch_bounds__(1024) void reduce_partials_k(const float* __restrict__ partial, int nblk, int d,
+                                                          void* __restrict__ out, int out_dt, int accumulate) {
+  // 32 columns per block; 32 row groups split the partial rows (fixed order and tree: deterministic).  With up to
+  // 1024 partial rows this is 32 independent loads per thread, 4 in flight, instead of 256 dependent ones.
+  __shared__ float red[32][33];
+  const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < d) {
+    int b = g;
+    for (; b + 96 < nblk; b += 128) {
+      s0 += partial[(int64_t)b * d + e];
+      s1 += partial[(int64_t)(b + 32) * d + e];
+      s2 += partial[(int64_t)(b + 64) * d + e];
+      s3 += partial[(int64_t)(b + 96) * d + e];
+    }
+    for (; b < nblk; b += 32) s0 += partial[(int64_t)b * d + e];
+  }
+  red[g][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g != 0 || e >= d) return;
-  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += red[i][col];
   if (out_dt == MH_F32) {
     float* o = (float*)out;
     o[e] = accumulate ? o[e] + s : s;
@@ -305,11 +316,11 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* w, const void* dy, vo
 
 extern "C" int mh_reduce_partials(const float* partial, int nblk, int d, void* out, int dt, int accumulate, void* stream) {
   if (!partial || !out || nblk <= 0 || d <= 0) return MH_ERR_ARG;
-  const int grid = (d + 63) / 64;
+  const int grid = (d + 31) / 32;
   if (dt == MH_F16)
-    hipLaunchKernelGGL(reduce_partials_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
+    hipLaunchKernelGGL(reduce_partials_k<MH_F16>, dim3(grid), dim3(1024), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
   else
-    hipLaunchKernelGGL(reduce_partials_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
+    hipLaunchKernelGGL(reduce_partials_k<MH_BF16>, dim3(grid), dim3(1024), 0, as_stream(stream), partial, nblk, d, out, dt, accumulate);
   MH_LAUNCH_CHECK();
 }
 

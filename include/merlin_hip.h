@@ -67,9 +67,21 @@ int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 /* General form: each operand is K-contiguous (x_kstrided = 0: A[M,K] / B[N,K]) or K-strided (1: A[K,M] / B[K,N],
  * i.e. the non-contracted index is the contiguous one).  C[M,N] = op(A) * op(B)^T as above.  Backward GEMMs need
  * no transposed copies: dgrad dX[T,Kin] = dY[T,Nout] * W[Nout,Kin] is (A=dY, B=W K-strided); wgrad dW[Nout,Kin] =
- * dY^T * X is (A=dY K-strided, B=X K-strided, K = T).  K-strided operands need M (resp. N) % 8 == 0. */
+ * dY^T * X is (A=dY K-strided, B=X K-strided, K = T).  K-strided operands need M (resp. N) % 8 == 0; K % 64 == 0
+ * unless BOTH operands are K-strided (then any K: the tail rows are read as zeros). */
 int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C, int64_t ldc,
             const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt, int epilogue, void* stream);
+
+/* Split-K form for weight gradients whose output is small next to the contraction (CLIP tower: dW[<=4096, <=4096]
+ * over K = 27 696 tokens gives only 16-64 output tiles for 256 CUs): `splits` blocks share an output tile, each
+ * reduces its own K range into an fp32 partial tile in `ws` (splits * M * N floats), then one pass adds the
+ * partials (fixed order: deterministic) into C (`dt` or fp32, optionally += C).  mh_gemm_splitk_max returns the
+ * split count the library would use for a shape (1 = not worth splitting).  With both operands K-strided, K may be
+ * any positive value: rows k >= K of the last K-tile are read as zeros. */
+int mh_gemm_splitk_max(int M, int N, int K);
+int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
+                   int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
+                   void* stream);
 
 /* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip,
  * else 128x128), 128 or 256 = force that tile. */

@@ -154,11 +154,87 @@ extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
   return mh_gemm(A, lda, 0, B, ldb, 0, C, ldc, bias, resid, ldr, M, N, K, dt, epilogue, stream);
 }
 
+__device__ uint16_t g_zero_row[512];  // zero-initialised: stands in for K-strided rows k >= K (see gemm256.hip)
+
+// sum of `splits` fp32 partial tiles -> 16-bit or fp32 C (+ old C): 4 consecutive elements per thread
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ ws, int splits, int64_t split_stride, void* C,
+                                                       int64_t ldc, int M, int N, int out_f32, int accumulate) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // quad index over M * N/4
+  const int nq = N >> 2;
+  if (q >= (int64_t)M * nq) return;
+  const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+  float4 s = *(const float4*)(ws + (int64_t)m * N + n);
+  for (int i = 1; i < splits; ++i) {
+    const float4 t = *(const float4*)(ws + i * split_stride + (int64_t)m * N + n);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  if (out_f32) {
+    float4* dst = (float4*)((float*)C + (int64_t)m * ldc + n);
+    if (accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *dst = s;
+  } else {
+    uint2* dst = (uint2*)((uint16_t*)C + (int64_t)m * ldc + n);
+    if (accumulate) {
+      const uint2 o = *dst;
+      float o0, o1, o2, o3;
+      unpack2<DT>(o.x, o0, o1);
+      unpack2<DT>(o.y, o2, o3);
+      s.x += o0; s.y += o1; s.z += o2; s.w += o3;
+    }
+    *dst = make_uint2(pack2<DT>(s.x, s.y), pack2<DT>(s.z, s.w));
+  }
+}
+
+static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
+                     int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
+                     int epilogue, int splits, int64_t c_split, void* stream);
+
 extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                        int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
                        int epilogue, void* stream) {
+  return gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, C, ldc, bias, resid, ldr, M, N, K, dt, epilogue, 1, 0, stream);
+}
+
+extern "C" int mh_gemm_splitk_max(int M, int N, int K) {
+  const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+  const int nk = (K + BK - 1) / BK;
+  if (tiles >= 128 || nk < 16) return 1;
+  int s = (int)(256 / tiles);  // one round of blocks: tiles * s <= 256 CUs
+  if (s > 16) s = 16;
+  while (s > 1 && (nk + s - 1) / s < 8) --s;           // >= 8 K-tiles per split
+  while (s > 1 && (s - 1) * ((nk + s - 1) / s) >= nk) --s;  // no empty split
+  return s;
+}
+
+extern "C" int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
+                              int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
+                              void* stream) {
+  if (splits < 1 || splits > 64) return MH_ERR_ARG;
+  if (splits == 1)
+    return gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, C, ldc, nullptr, nullptr, 0, M, N, K, dt,
+                     (accumulate ? MH_EPI_ACCUM : 0) | (out_f32 ? MH_EPI_OUT_F32 : 0), 1, 0, stream);
+  if (!ws || (N & 3) || (ldc & 3)) return MH_ERR_ARG;
+  const int nk = (K + BK - 1) / BK;
+  if ((int64_t)(splits - 1) * ((nk + splits - 1) / splits) >= nk) return MH_ERR_ARG;  // an empty split
+  const int rc = gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, ws, N, nullptr, nullptr, 0, M, N, K, dt, MH_EPI_OUT_F32, splits,
+                           (int64_t)M * N, stream);
+  if (rc != MH_OK) return rc;
+  const int64_t quads = (int64_t)M * (N >> 2);
+  const unsigned grid = (unsigned)((quads + 255) / 256);
+  if (dt == MH_F16)
+    hipLaunchKernelGGL(splitk_reduce_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, C, ldc, M, N, out_f32, accumulate);
+  else
+    hipLaunchKernelGGL(splitk_reduce_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, C, ldc, M, N, out_f32, accumulate);
+  MH_LAUNCH_CHECK();
+}
+
+static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
+                     int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
+                     int epilogue, int splits, int64_t c_split, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
-  if (K % BK != 0 || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B)) return MH_ERR_ARG;
+  const bool both_ks = a_kstrided && b_kstrided;  // the only form whose K need not be a multiple of 64 (zero rows)
+  if ((!both_ks && K % BK != 0) || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B)) return MH_ERR_ARG;
   if ((a_kstrided && (M & 7)) || (b_kstrided && (N & 7))) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_RESIDUAL) && !resid) return MH_ERR_ARG;
@@ -168,6 +244,12 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B
   g.bias = (const uint16_t*)bias; g.resid = (const uint16_t*)resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+  g.splits = splits; g.c_split = c_split;
+  {
+    static void* zp = nullptr;
+    if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
+    g.zero_row = (const uint16_t*)zp;
+  }
   const bool f32out = epilogue & MH_EPI_OUT_F32;
   g.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)C) & (f32out ? 15u : 7u)) == 0) &&
              (!(epilogue & MH_EPI_RESIDUAL) || ((ldr % 4 == 0) && ((((uintptr_t)resid) & 7u) == 0))) &&
@@ -183,17 +265,17 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
-  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided) {  // A/B arm: MFMA 32x32x16 fragments
+  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1) {  // A/B arm: MFMA 32x32x16 fragments
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
+  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
   }
-  if (big || a_kstrided || b_kstrided) {  // K-strided operands exist only in the 8-wave 256-tile kernel
+  if (big || a_kstrided || b_kstrided || splits > 1) {  // K-strided operands / split-K exist only in the 8-wave 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_256(g, dt, a_kstrided, b_kstrided, as_stream(stream));

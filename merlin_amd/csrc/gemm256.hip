@@ -113,7 +113,7 @@ __device__ __forceinline__ void read_frags_tr(FR& fr, const unsigned* at) {
   } while (0)
 
 template <int DT, bool AKS, bool BKS>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by value: the split-K block offsets its own copy)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,7 +121,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
   int tm, tn;
   tile_of_block(g, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = g.K / BK;
+  // split-K: block y of grid.y takes K-tiles [kt0, kt0 + nk) and writes its own fp32 partial tile
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int per_split = (nk_total + g.splits - 1) / g.splits;
+  const int kt0 = blockIdx.y * per_split;
+  const int nk = min(per_split, nk_total - kt0);
+  if (g.splits > 1) g.C = (float*)g.C + (int64_t)blockIdx.y * g.c_split;
+  // K % 64 != 0 (both operands K-strided only): rows k >= K of the last K-tile are read from a row of zeros
+  const int k_tail = g.K - (nk_total - 1) * BK;  // valid rows of the global last K-tile (64 when K % 64 == 0)
 
   // staging sources: half-tile h, instruction i: 16-byte chunk qd = i*512 + tid of the half-tile's 1024
   const uint16_t* src[4][2];
@@ -153,13 +160,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {
   }
   const int64_t a_kstep = AKS ? (int64_t)BK * g.lda : (int64_t)BK;  // elements per K-tile
   const int64_t b_kstep = BKS ? (int64_t)BK * g.ldb : (int64_t)BK;
+  const uint16_t* zsrc = g.zero_row + lane * 8;
+  const bool ztail[2] = {(AKS && BKS) && ((tid >> 4) >= k_tail), (AKS && BKS) && (((512 + tid) >> 4) >= k_tail)};
   // issue half-tile h of K-tile kt (kt clamped to the last tile: uniform load count; the re-loads of the
   // tail only ever target slots nobody reads again)
   auto issue = [&](int h, int kt) {
-    const int64_t koff = (int64_t)min(kt, nk - 1) * (h < 2 ? a_kstep : b_kstep);
+    const int ktc = kt0 + min(kt, nk - 1);
+    const int64_t koff = (int64_t)ktc * (h < 2 ? a_kstep : b_kstep);
     char* dst = smem + (kt & 1) * STAGE256 + h * HALF_BYTES + wave * 1024;
-    glds16(src[h][0] + koff, dst);
-    glds16(src[h][1] + koff, dst + 8192);
+    if constexpr (AKS && BKS) {
+      const bool last = (ktc == nk_total - 1);
+      glds16((last && ztail[0]) ? zsrc : src[h][0] + koff, dst);
+      glds16((last && ztail[1]) ? zsrc : src[h][1] + koff, dst + 8192);
+    } else {
+      glds16(src[h][0] + koff, dst);
+      glds16(src[h][1] + koff, dst + 8192);
+    }
   };
 
   f32x4_t acc[2][4][2][2];  // [mh][i][nh][j]
@@ -316,7 +332,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt_256<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS256, stream, g);
+  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n, g.splits), dim3(512), LDS256, stream, g);
   MH_LAUNCH_CHECK();
 }
 

@@ -12,13 +12,16 @@ struct GemmArgs {
   const uint16_t* resid;
   int64_t lda, ldb, ldc, ldr;
   int M, N, K, epi, tiles_m, tiles_n, vec_ok;
+  int splits;              // split-K: grid.y blocks share a tile, block y writes fp32 partials to C + y*c_split
+  int64_t c_split;         // elements between the partial outputs of consecutive splits
+  const uint16_t* zero_row;  // >= 1 KiB of zeros: source of K-strided rows k >= K in the last K-tile
 };
 
 constexpr int BK = 64;
 
 // block id -> (tm, tn)
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tm, int& tn) {
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = gridDim.x, bid = blockIdx.x;  // (split-K uses gridDim.y)
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   constexpr int GM = 8;

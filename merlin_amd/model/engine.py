@@ -162,10 +162,11 @@ class HipEngine:
 
     def _wgrad(self, dy, x, gout, fresh, Tpad):
         """gout[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in].  The contraction runs over tokens, so both operands
-        are K-strided as they lie in memory: the MFMA kernel reads them with transpose-reads, no copies.
-        (T % 64 != 0: re-lay both out with a zero-padded K instead.)"""
-        if dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
-            O.gemm_nt(dy, x, a_t=True, b_t=True, out=gout, accum=not fresh)
+        are K-strided as they lie in memory: the MFMA kernel reads them with transpose-reads, no copies, any T
+        (the CLIP tower's 27 696 tokens are not a multiple of the 64-token K-tile), split-K for the small CLIP
+        weights.  Odd feature widths (not a multiple of 8) fall back to zero-padded transposed copies."""
+        if dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+            O.wgrad_tn(dy, x, gout, accum=not fresh)
             return
         dyT = O.transpose16(dy, r_pad=Tpad)
         xT = O.transpose16(x, r_pad=Tpad)

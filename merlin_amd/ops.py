@@ -124,6 +124,32 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
     return out
 
 
+_splitk_ws = {}
+
+
+def wgrad_tn(dy, x, out, accum):
+    """out[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in]: both operands K-strided as they lie in memory, any T (the
+    kernel reads rows >= T of the last K-tile as zeros), split-K when the output has too few tiles to fill the chip."""
+    T, M = dy.shape
+    T2, N = x.shape
+    assert T == T2 and dy.dtype == x.dtype and M % 8 == 0 and N % 8 == 0
+    lda, ldb, ldc = _rowmajor(dy), _rowmajor(x), _rowmajor(out)
+    splits = int(L.lib().mh_gemm_splitk_max(i32(M), i32(N), i32(T)))
+    ws = None
+    if splits > 1:
+        key = (dy.device, splits * M * N)
+        ws = _splitk_ws.get(key)
+        if ws is None:
+            if len(_splitk_ws) > 8:
+                _splitk_ws.clear()
+            ws = _splitk_ws[key] = torch.empty(splits * M * N, dtype=torch.float32, device=dy.device)
+    with _timed("gemm_nt", 2.0 * M * N * T):
+        L.check(L.lib().mh_gemm_splitk(p(dy), i64(lda), i32(1), p(x), i64(ldb), i32(1), p(out), i64(ldc), i32(M), i32(N), i32(T),
+                                       i32(dt_of(dy)), i32(int(accum)), i32(int(out.dtype == torch.float32)), i32(splits), p(ws),
+                                       _stream()), "mh_gemm_splitk")
+    return out
+
+
 def transpose16(x, r_pad=None, out=None):
     """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
     R, Cc = x.shape

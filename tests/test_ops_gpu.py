@@ -396,6 +396,35 @@ def test_gemm_kstrided_operands(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,No,Ki", [(27696, 1024, 1024), (27696, 3072, 1024), (1731, 1024, 256), (130, 512, 264), (64, 256, 256),
+                                     (4100, 4096, 4096), (8192, 1024, 4096), (37, 256, 8)])
+def test_wgrad_tn_any_tokens_splitk(ops, dtype, T, No, Ki):
+    """Weight gradient dW[No, Ki] (+)= dY[T, No]^T X[T, Ki] with the token count as the contraction: any T (zero-row
+    tail of the last K-tile), split-K for outputs too small to fill the chip (CLIP tower shapes), fresh and
+    accumulating, bit-identical run to run (fixed reduction order)."""
+    dy, x = rnd(T, No, dtype=dtype, scale=0.5), rnd(T, Ki, dtype=dtype, seed=1, scale=0.5)
+    ref = dy.float().t() @ x.float()
+    out = torch.empty(No, Ki, dtype=dtype, device=dev())
+    ops.wgrad_tn(dy, x, out, accum=False)
+    assert relerr(out, ref) < 3 * EPS16[dtype]
+    first = out.clone()
+    for _ in range(2):
+        ops.wgrad_tn(dy, x, out, accum=False)
+        assert torch.equal(out, first)
+    old = rnd(No, Ki, dtype=dtype, seed=5)
+    acc = old.clone()
+    ops.wgrad_tn(dy, x, acc, accum=True)
+    assert relerr(acc, ref + old.float()) < 4 * EPS16[dtype]
+    acc32 = torch.ones(No, Ki, device=dev())
+    ops.wgrad_tn(dy, x, acc32, accum=True)
+    assert relerr(acc32, ref + 1) < 2e-5
+    # a strided view of a wider buffer (fused q|k|v gradient spans are written as views)
+    wide = torch.zeros(No, Ki + 64, dtype=dtype, device=dev())
+    ops.wgrad_tn(dy, x, wide[:, 8:8 + Ki], accum=False)
+    assert torch.equal(wide[:, 8:8 + Ki], first) and float(wide[:, :8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1000, 515, 256), (613, 4096, 1024),
                                    (2048, 2048, 4096), (300, 103, 64), (4096, 11008, 512)])
 @pytest.mark.parametrize("which", [256, 4])

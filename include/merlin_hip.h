@@ -154,6 +154,24 @@ int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
                 void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* ws,
                 const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
 
+/* ---- KV-cache decode (S_q = 1): generate() behind llama_mmgpt.py:114-134 / eval_mmvet.py:101-120 ------------------
+ * HF LlamaAttention with past_key_values (modeling_llama.py:243-281): q,k of the new token rotated at its own
+ * position, k,v appended to the cache, softmax(q K^T / sqrt(D)) V over keys [0, len).  All HBM-bound kernels. */
+/* y[m, n] = sum_k x[m, k] W[n, k] (+ resid[m, n]); M <= 8 activation rows against a weight streamed once; out is `dt`
+ * or fp32.  K % 8 == 0, 16-byte aligned rows. */
+int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid, int64_t ldr,
+            int M, int N, int K, int dt, int out_f32, void* stream);
+/* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
+ * kcache / vcache [B, Smax, H*D] at row pos[b]. */
+int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,
+                          int D, int Smax, int dt, void* stream);
+/* out[b, h*D..] = softmax(q[b,h] . K[b, 0..lens[b]) / sqrt(D)) V[b, 0..lens[b]);  q row stride ldq; D in {64, 128}.
+ * Split-KV: with ws != NULL (B*H*mh_attn_decode_splits(B,H,Smax)*(D+2) floats) several blocks share one (b, h) and a
+ * second pass merges their partial softmaxes; ws == NULL runs one block per (b, h). */
+int mh_attn_decode_splits(int B, int H, int Smax);
+int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, void* out, const int32_t* lens,
+                   int B, int H, int D, int Smax, float* ws, int dt, void* stream);
+
 /* ---- CLIP patch embedding ------------------------------------------------------------- */
 /* cols[n*G*G + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad.
  * pixels fp32 (pix_dt = MH_F32) or 16-bit; cols `dt`.  clip_encoder.py:76-79 -> CLIPVisionEmbeddings. */

@@ -1,0 +1,309 @@
+// KV-cache decode step of the Llama decoder (gfx950): the S_q = 1 path behind `generate()`
+// (reference: llama_mmgpt.py:114-134 prepare_inputs_for_generation; HF LlamaAttention with past_key_values,
+// modeling_llama.py:243-281; eval_mmvet.py:101-120 is the caller).  Every kernel here is HBM-bound - one new token
+// per sequence streams all weights (13.5 GB for Llama-7B) and the whole K/V cache once - so none of it is shaped
+// into an MFMA GEMM: the rules that matter are 16-byte coalesced loads, enough waves in flight and no re-reads.
+//
+//   mh_gemv             y[m, n] = sum_k x[m, k] W[n, k] (+ resid[m, n]),  m <= 8 rows: ONE WAVE PER WEIGHT ROW, the
+//                       row is read once as 64 lanes x 16 B per step and dotted against all m activations rows
+//                       (which stay in L1/L2: m * K * 2 B <= 176 KB); fp32 accumulate, shuffle reduction.
+//   mh_decode_rope_append  rotate q, k of the new token at its own position (rotate-half, as mh_rope_qk) and append
+//                       k, v to the cache rows [b, pos[b]].
+//   mh_attn_decode      block per (b, h, key split): pass 1 D/8 lanes per key (coalesced 256-B key rows, shuffle-reduced
+//                       dot products) -> scores in LDS -> block max / sum; pass 2 lane-per-channel accumulation of
+//                       p.V (coalesced value rows); split-KV partials merged by a second kernel.  Keys [0, len[b]).
+#include "mh_common.h"
+
+namespace {
+
+// packed dot product of two 16-bit pairs with fp32 accumulate (v_dot2c_f32_bf16 / v_dot2c_f32_f16): no unpacking, half
+// the VALU instructions of an fma per element - at 8 activation rows the unpack+fma form is VALU-bound, not HBM-bound
+typedef __bf16 mh_bf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mh_h2 __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
+  if constexpr (DT == MH_BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mh_bf2, a), __builtin_bit_cast(mh_bf2, b), c, false);
+  else return __builtin_amdgcn_fdot2(__builtin_bit_cast(mh_h2, a), __builtin_bit_cast(mh_h2, b), c, false);
+}
+
+// ROWS weight rows per wave: an activation chunk (MM x 8 values) is loaded once and used against ROWS weight rows,
+// so for MM = 8 the L1 traffic of the activations drops from 8x to 2x the weight stream.
+template <int DT, int MM, int ROWS>
+__global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
+                                              int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
+                                              int64_t ldr, int N, int K, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (n0 >= N) return;
+  float acc[ROWS][MM];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const uint16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (int64_t)min(n0 + r, N - 1) * ldw;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    uint4 wv[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wv[r] = *(const uint4*)(wrow[r] + k0);
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const uint4 xv = *(const uint4*)(x + (int64_t)m * ldx + k0);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        float a = acc[r][m];
+        a = dot2_acc<DT>(wv[r].x, xv.x, a);
+        a = dot2_acc<DT>(wv[r].y, xv.y, a);
+        a = dot2_acc<DT>(wv[r].z, xv.z, a);
+        a = dot2_acc<DT>(wv[r].w, xv.w, a);
+        acc[r][m] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        float v = acc[r][m];
+        if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+        if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+        else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+      }
+    }
+  }
+}
+
+// qkv [B, 3, H, D] of the new tokens; tab [max_pos, D/2] (cos, sin); kc, vc [B, Smax, H*D]
+template <int DT>
+__global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv, const float2* __restrict__ tab,
+                                                     const int32_t* __restrict__ pos, uint16_t* __restrict__ kc,
+                                                     uint16_t* __restrict__ vc, int B, int H, int D, int Smax) {
+  const int half = D >> 1, vph = half >> 3;
+  const int64_t total = (int64_t)B * H * vph;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)(i % vph);
+  const int h = (int)((i / vph) % H);
+  const int b = (int)(i / ((int64_t)vph * H));
+  const int p = pos[b];
+  const float2* tb = tab + (int64_t)p * half + v * 8;
+  const int64_t hd = (int64_t)h * D + v * 8;
+  uint16_t* qb = qkv + (int64_t)b * 3 * H * D + hd;
+  uint16_t* kb = qb + (int64_t)H * D;
+  const uint16_t* vb = kb + (int64_t)H * D;
+  uint16_t* kdst = kc + ((int64_t)b * Smax + p) * H * D + hd;
+  uint16_t* vdst = vc + ((int64_t)b * Smax + p) * H * D + hd;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    uint16_t* base = which ? kb : qb;
+    float lo[8], hi[8];
+    unpack8<DT>(*(const uint4*)base, lo);
+    unpack8<DT>(*(const uint4*)(base + half), hi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float c = tb[k].x, s = tb[k].y;
+      const float a = lo[k], bb = hi[k];
+      lo[k] = a * c - bb * s;
+      hi[k] = bb * c + a * s;
+    }
+    const uint4 plo = pack8<DT>(lo), phi = pack8<DT>(hi);
+    *(uint4*)base = plo;
+    *(uint4*)(base + half) = phi;
+    if (which) {
+      *(uint4*)kdst = plo;
+      *(uint4*)(kdst + half) = phi;
+    }
+  }
+  *(uint4*)vdst = *(const uint4*)vb;
+  *(uint4*)(vdst + half) = *(const uint4*)(vb + half);
+}
+
+// q [B, ldq] (head h at h*D); kc, vc [B, Smax, H*D]; out [B, H*D]; keys [0, len[b]).  D in {64, 128}.
+// Split-KV ("flash decoding"): with B*H blocks only (32 at batch 1) the cache streams at a few % of HBM speed, so
+// `splits` blocks share one (b, h), each takes `chunk` keys and leaves (unnormalised o[D], max, sum) in `ws`;
+// attn_decode_combine_k merges them.  splits == 1 writes the normalised result directly.
+template <int DT, int D>
+__global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kc,
+                                                     const uint16_t* __restrict__ vc, uint16_t* __restrict__ out,
+                                                     const int32_t* __restrict__ lens, int H, int Smax, float scale_log2,
+                                                     int splits, int chunk, float* __restrict__ ws) {
+  extern __shared__ float sc[];  // [chunk] scores, then [G][D] partial outputs
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x % splits;
+  const int h = (blockIdx.x / splits) % H, b = blockIdx.x / (splits * H);
+  const int key0 = sp * chunk;
+  const int len = max(0, min(min(lens[b], Smax) - key0, chunk));  // keys [key0, key0 + len) of this split
+  kc += (int64_t)key0 * H * D;
+  vc += (int64_t)key0 * H * D;
+  const int64_t HD = (int64_t)H * D;
+  // pass 1: D/8 lanes per key (one 16-byte piece each: a key row is one coalesced 256-byte read), 256*8/D keys per
+  // block iteration; the partial dot products are summed across the lane group by shuffles
+  constexpr int OCT1 = D / 8, KPI = 256 / OCT1;
+  const int kpart = tid % OCT1, ksub = tid / OCT1;
+  float q8[8];
+  unpack8<DT>(*(const uint4*)(q + (int64_t)b * ldq + (int64_t)h * D + kpart * 8), q8);
+  float mx = -1e30f;
+  for (int j0 = 0; j0 < len; j0 += KPI) {
+    const int j = j0 + ksub;
+    float s = 0.f;
+    if (j < len) {
+      float kv[8];
+      unpack8<DT>(*(const uint4*)(kc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + kpart * 8), kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(q8[e], kv[e], s);
+    }
+#pragma unroll
+    for (int o2 = OCT1 / 2; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
+    s *= scale_log2;
+    if (j < len) {
+      if (kpart == 0) sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int j = tid; j < len; j += 256) {
+    const float pj = fast_exp2(sc[j] - mx);
+    sc[j] = pj;
+    sum += pj;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  // pass 2: thread = (key slice g of 256*8/D, channel octet c); 8 channels per thread
+  constexpr int OCT = D / 8;       // octets per value row
+  constexpr int G = 256 / OCT;     // key slices
+  const int c = tid % OCT, gsl = tid / OCT;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j = gsl; j < len; j += G) {
+    const float pj = sc[j];
+    float vv[8];
+    unpack8<DT>(*(const uint4*)(vc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + c * 8), vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vv[e], o[e]);
+  }
+  __syncthreads();  // everyone is done reading the scores: reuse the buffer for the slice partials
+  float* part = sc;  // [G][D]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[gsl * D + c * 8 + e] = o[e];
+  __syncthreads();
+  if (tid < D) {
+    float a = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) a += part[g2 * D + tid];
+    if (splits == 1) {
+      out[(int64_t)b * HD + (int64_t)h * D + tid] = (uint16_t)st16<DT>(len > 0 ? a / sum : 0.f);
+    } else {
+      float* w = ws + ((int64_t)(b * H + h) * splits + sp) * (D + 2);
+      w[tid] = a;
+      if (tid == 0) { w[D] = mx; w[D + 1] = sum; }
+    }
+  }
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restrict__ ws, uint16_t* __restrict__ out, int H, int splits) {
+  const int bh = blockIdx.x, tid = threadIdx.x;
+  const float* w = ws + (int64_t)bh * splits * (D + 2);
+  float M = -1e30f;
+  for (int s2 = 0; s2 < splits; ++s2) M = fmaxf(M, w[s2 * (D + 2) + D]);
+  float num = 0.f, den = 0.f;
+  for (int s2 = 0; s2 < splits; ++s2) {
+    const float f = fast_exp2(w[s2 * (D + 2) + D] - M);
+    num += w[s2 * (D + 2) + tid] * f;
+    den += w[s2 * (D + 2) + D + 1] * f;
+  }
+  out[(int64_t)bh * D + tid] = (uint16_t)st16<DT>(den > 0.f ? num / den : 0.f);
+}
+
+}  // namespace
+
+extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
+                       int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+  if (!x || !W || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
+  if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int rows = M >= 3 ? 4 : 2;  // weight rows per wave
+  const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
+  hipStream_t st = as_stream(stream);
+#define GO(DT_, MM_, R_)                                                                                                     \
+  hipLaunchKernelGGL((gemv_k<DT_, MM_, R_>), grid, block, 0, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
+                     (const uint16_t*)resid, ldr, N, K, out_f32)
+#define GOM(DT_)                                                                                                       \
+  switch (M) {                                                                                                         \
+    case 1: GO(DT_, 1, 2); break; case 2: GO(DT_, 2, 2); break; case 3: GO(DT_, 3, 4); break; case 4: GO(DT_, 4, 4); break; \
+    case 5: GO(DT_, 5, 4); break; case 6: GO(DT_, 6, 4); break; case 7: GO(DT_, 7, 4); break; default: GO(DT_, 8, 4); break; \
+  }
+  if (dt == MH_BF16) { GOM(MH_BF16) } else { GOM(MH_F16) }
+#undef GOM
+#undef GO
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B,
+                                     int H, int D, int Smax, int dt, void* stream) {
+  if (!qkv || !cos_sin || !pos || !kcache || !vcache || B <= 0 || H <= 0 || (D & 15) || Smax <= 0) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int64_t total = (int64_t)B * H * (D / 16);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(rope_append_k<MH_BF16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos,
+                       (uint16_t*)kcache, (uint16_t*)vcache, B, H, D, Smax);
+  else
+    hipLaunchKernelGGL(rope_append_k<MH_F16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos,
+                       (uint16_t*)kcache, (uint16_t*)vcache, B, H, D, Smax);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_attn_decode_splits(int B, int H, int Smax) {
+  int s = (512 + B * H - 1) / (B * H);
+  const int by_len = (Smax + 255) / 256;  // >= 256 keys per split
+  if (s > by_len) s = by_len;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, void* out, const int32_t* lens,
+                              int B, int H, int D, int Smax, float* ws, int dt, void* stream) {
+  if (!q || !kcache || !vcache || !out || !lens || B <= 0 || H <= 0 || Smax <= 0 || (ldq & 7)) return MH_ERR_ARG;
+  if (D != 128 && D != 64) return MH_ERR_SHAPE;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const float scale_log2 = 1.4426950408889634f / sqrtf((float)D);
+  const int splits = ws ? mh_attn_decode_splits(B, H, Smax) : 1;
+  const int chunk = (Smax + splits - 1) / splits;
+  const int G = 256 / (D / 8);
+  const size_t lds = sizeof(float) * (size_t)((chunk > G * D) ? chunk : G * D);
+  if (lds > 150 * 1024) return MH_ERR_SHAPE;  // <= 38400 keys per split
+  const dim3 grid(B * H * splits), block(256);
+  hipStream_t st = as_stream(stream);
+#define GO(DT_, D_)                                                                                                     \
+  do {                                                                                                                   \
+    static bool attr = false;                                                                                           \
+    if (!attr) {                                                                                                         \
+      hipFuncSetAttribute((const void*)attn_decode_k<DT_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((attn_decode_k<DT_, D_>), grid, block, lds, st, (const uint16_t*)q, ldq, (const uint16_t*)kcache, \
+                       (const uint16_t*)vcache, (uint16_t*)out, lens, H, Smax, scale_log2, splits, chunk, ws);           \
+    if (splits > 1)                                                                                                      \
+      hipLaunchKernelGGL((attn_decode_combine_k<DT_, D_>), dim3(B * H), dim3(D_), 0, st, (const float*)ws, (uint16_t*)out, H, splits); \
+  } while (0)
+  if (dt == MH_BF16) { if (D == 128) GO(MH_BF16, 128); else GO(MH_BF16, 64); }
+  else { if (D == 128) GO(MH_F16, 128); else GO(MH_F16, 64); }
+#undef GO
+  MH_LAUNCH_CHECK();
+}

@@ -368,7 +368,7 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     # Llama
     # ------------------------------------------------------------------------------------------
-    def _llama_layer_fwd(self, W, x, B, S, lens, keep):
+    def _llama_layer_fwd(self, W, x, B, S, lens, keep, kv_out=None):
         cfg = self.model.config
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         eps = cfg.rms_norm_eps
@@ -376,6 +376,9 @@ class HipEngine:
         qkv = O.gemm_nt(h1, W.wqkv)
         O.rope_qk_(qkv, self.rope, S, H, D)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        if kv_out is not None:  # prefill: rotated keys and values go to the decode cache [B, Smax, d]
+            kv_out[0][:, :S].copy_(k.view(B, S, d))
+            kv_out[1][:, :S].copy_(v.view(B, S, d))
         o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         x2 = O.gemm_nt(o, W.wo, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
@@ -464,7 +467,8 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     # public entry points
     # ------------------------------------------------------------------------------------------
-    def forward(self, input_ids, attention_mask, labels, images, inputs_embeds=None, want_grad=False, loss_only=False):
+    def forward(self, input_ids, attention_mask, labels, images, inputs_embeds=None, want_grad=False, loss_only=False,
+                kv_cache=None, last_only=False):
         """Returns (loss fp32 scalar tensor | None, logits fp32 [B,S,V] view | None, ctx)."""
         m = self.model
         cfg = m.config
@@ -508,10 +512,11 @@ class HipEngine:
         del feats
         # ---- decoder ----
         xs, saves = [], []
-        for W in self.llama:
+        for li, W in enumerate(self.llama):
             if want_grad:
                 xs.append(x)
-            x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations)
+            x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations,
+                                          kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None)
             saves.append(sv)
         ctx.update(xs=xs, saves=saves, x_last=x if want_grad else None)
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), cfg.rms_norm_eps)
@@ -519,6 +524,10 @@ class HipEngine:
         V = cfg.vocab_size
         Vpad = _ru(V, 64)
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
+        if last_only:  # prefill of generate(): only each sequence's last valid position feeds the sampler
+            last = (lens.to(torch.int64) - 1) if lens is not None else torch.full((B,), S - 1, dtype=torch.int64, device=dev)
+            rows = hn.index_select(0, torch.arange(B, device=dev) * S + last.clamp_min(0))
+            return None, O.gemv(rows, wlm, out_f32=True, n=V), ctx
         logits = O.gemm_nt(hn, wlm, out_f32=True)  # [T, Vpad] fp32
         loss = None
         if labels is not None:
@@ -607,6 +616,60 @@ class HipEngine:
                     if dead or untrained_tower or unused_mm:
                         A.gview(n).zero_()
         self._ready(None)  # end of backward
+
+    # ------------------------------------------------------------------------------------------
+    # KV-cache decode (llama_mmgpt.py:114-134, HF LlamaAttention with past_key_values)
+    # ------------------------------------------------------------------------------------------
+    class KVCache:
+        """Per-layer rotated keys and values, [B, Smax, H*D] each, plus the valid length of every sequence."""
+
+        def __init__(self, n_layers, B, Smax, d, dtype, device):
+            self.k = [torch.zeros(B, Smax, d, dtype=dtype, device=device) for _ in range(n_layers)]
+            self.v = [torch.zeros(B, Smax, d, dtype=dtype, device=device) for _ in range(n_layers)]
+            self.lens = torch.zeros(B, dtype=torch.int32, device=device)
+            self.B, self.Smax = B, Smax
+
+    def prefill(self, input_ids, attention_mask, images, max_new_tokens, inputs_embeds=None):
+        """Full forward over the prompt that also fills a KV cache; returns (logits fp32 [B, V] at each sequence's last
+        valid position, cache).  Right-padded prompts (attention_mask) decode from their own length."""
+        self.ensure_arena()
+        cfg = self.model.config
+        B, S = (input_ids.shape if input_ids is not None else inputs_embeds.shape[:2])
+        A = self.arena
+        cache = HipEngine.KVCache(len(self.llama), B, S + max_new_tokens, cfg.hidden_size, A.flat.dtype, A.flat.device)
+        self._rope_table(S + max_new_tokens, A.flat.device)
+        _, logits, ctx = self.forward(input_ids, attention_mask, None, images, inputs_embeds=inputs_embeds, kv_cache=cache,
+                                      last_only=True)
+        lens = ctx["lens"]
+        cache.lens.copy_(lens if lens is not None else torch.full((B,), S, dtype=torch.int32, device=A.flat.device))
+        return logits, cache
+
+    def decode_step(self, tokens, cache):
+        """One new token per sequence (tokens int64 [B]) at position cache.lens[b]; returns logits fp32 [B, V] and
+        advances the cache.  Every op is an HBM-bound kernel: weights and cache are streamed exactly once."""
+        cfg = self.model.config
+        A = self.arena
+        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
+        eps = cfg.rms_norm_eps
+        emb = A.view("model.embed_tokens.weight", shape=(V, d))
+        x = emb.index_select(0, tokens.to(A.flat.device).view(-1))
+        pos = cache.lens
+        lens1 = pos + 1
+        for li, W in enumerate(self.llama):
+            h1 = O.rmsnorm_fwd(x, W.ln1, eps)
+            qkv = O.gemv(h1, W.wqkv)
+            O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
+            o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
+            x2 = O.gemv(o, W.wo, resid=x)
+            h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+            act = O.swiglu_fwd(O.gemv(h2, W.wgu))
+            x = O.gemv(act, W.wd, resid=x2)
+        hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
+        Vpad = _ru(V, 64)
+        wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
+        logits = O.gemv(hn, wlm, out_f32=True, n=V)
+        cache.lens = lens1
+        return logits
 
     # standalone sub-module calls (reference module surface; not used by the fused forward)
     def tower_forward_public(self, images):

@@ -221,21 +221,51 @@ class MMGPTLlamaForCausalLM(nn.Module):
         return model_inputs
 
     @torch.no_grad()
-    def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens=32, eos_token_id=None, do_sample=False, **kw):
-        """Greedy decoding by full-sequence recompute (no KV cache yet: SURVEY.md §8f row N3)."""
-        if do_sample:
-            raise NotImplementedError("sampling is not implemented; greedy only")
+    def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens=32, eos_token_id=None, do_sample=False,
+                 use_cache=True, num_beams=1, **kw):
+        """Greedy decoding (eval_mmvet.py:101-120 calls `model.generate(input_ids, images=[...], ...)`).
+        use_cache=True: one prefill over the prompt fills a KV cache, then one HBM-bound decode step per token
+        (llama_mmgpt.py:114-134 semantics: only the last token is fed, images are consumed by the prefill only).
+        use_cache=False: full-sequence recompute per token (kept as the cross-check).  Prompts may be right-padded
+        (attention_mask); finished sequences keep emitting eos.  Sampling and beam search are not implemented."""
+        if do_sample or num_beams != 1:
+            raise NotImplementedError("sampling / beam search are not implemented; greedy only")
         eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
-        ids = input_ids
-        for _ in range(max_new_tokens):
-            out = self.forward(input_ids=ids, attention_mask=attention_mask, images=images)
-            nxt = out.logits[:, -1, :].argmax(dim=-1, keepdim=True).to(ids.device)
-            ids = torch.cat([ids, nxt], dim=1)
-            if attention_mask is not None:
-                attention_mask = torch.cat([attention_mask, torch.ones_like(attention_mask[:, :1])], dim=1)
-            if eos is not None and bool((nxt == eos).all()):
+        if not use_cache:
+            ids = input_ids
+            for _ in range(max_new_tokens):
+                out = self.forward(input_ids=ids, attention_mask=attention_mask, images=images)
+                nxt = out.logits[:, -1, :].argmax(dim=-1, keepdim=True).to(ids.device)
+                ids = torch.cat([ids, nxt], dim=1)
+                if attention_mask is not None:
+                    attention_mask = torch.cat([attention_mask, torch.ones_like(attention_mask[:, :1])], dim=1)
+                if eos is not None and bool((nxt == eos).all()):
+                    break
+            return ids
+        logits, cache = self.engine.prefill(input_ids, attention_mask, images, max_new_tokens)
+        B = input_ids.shape[0]
+        done = torch.zeros(B, dtype=torch.bool, device=logits.device)
+        new = []
+        for step in range(max_new_tokens):
+            nxt = logits.argmax(dim=-1)
+            if eos is not None:
+                nxt = torch.where(done, torch.full_like(nxt, eos), nxt)
+                done = done | (nxt == eos)
+            new.append(nxt)
+            if step + 1 == max_new_tokens or (eos is not None and bool(done.all())):
                 break
-        return ids
+            logits = self.engine.decode_step(nxt, cache)
+        new = torch.stack(new, dim=1).to(input_ids.device)
+        if attention_mask is None:
+            return torch.cat([input_ids, new], dim=1)
+        # right-padded prompts: the continuation of each row starts at its own length
+        lens = attention_mask.to(torch.bool).sum(dim=1)
+        out = torch.full((B, input_ids.shape[1] + new.shape[1]), self.config.pad_token_id or 0, dtype=input_ids.dtype, device=input_ids.device)
+        for b in range(B):
+            lb = int(lens[b])
+            out[b, :lb] = input_ids[b, :lb]
+            out[b, lb:lb + new.shape[1]] = new[b]
+        return out
 
     # ---- construction helpers ----------------------------------------------------------------------
     @classmethod

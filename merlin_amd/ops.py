@@ -124,6 +124,43 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
     return out
 
 
+def gemv(x, w, out=None, resid=None, out_f32=False, n=None):
+    """out[M, N] = x[M, K] @ w[N, K]^T (+ resid) for M <= 8 rows per launch (decode step): weights streamed once."""
+    M, K = x.shape
+    N = w.shape[0] if n is None else n
+    assert w.shape[1] == K and x.dtype == w.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    for m0 in range(0, M, 8):
+        mm = min(8, M - m0)
+        xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
+        rs = resid[m0:m0 + mm] if resid is not None else None
+        L.check(L.lib().mh_gemv(p(xs), i64(_rowmajor(xs)), p(w), i64(_rowmajor(w)), p(os_), i64(_rowmajor(os_)), p(rs),
+                                i64(_rowmajor(rs) if rs is not None else 0), i32(mm), i32(N), i32(K), i32(dt_of(x)),
+                                i32(int(out.dtype == torch.float32)), _stream()), "mh_gemv")
+    return out
+
+
+def decode_rope_append(qkv, table, pos, kcache, vcache, H, D):
+    """qkv [B, 3*H*D] of the new tokens (rotated in place at pos[b]); k, v appended to kcache/vcache [B, Smax, H*D]."""
+    B = qkv.shape[0]
+    assert qkv.is_contiguous() and pos.dtype == torch.int32 and kcache.is_contiguous() and vcache.is_contiguous()
+    L.check(L.lib().mh_decode_rope_append(p(qkv), p(table), p(pos), p(kcache), p(vcache), i32(B), i32(H), i32(D),
+                                          i32(kcache.shape[1]), i32(dt_of(qkv)), _stream()), "mh_decode_rope_append")
+
+
+def attn_decode(q, kcache, vcache, lens, H, D, out=None, split_kv=True):
+    """q [B, H*D] view (row stride ldq) against the cache [B, Smax, H*D]; keys [0, lens[b])."""
+    B = q.shape[0]
+    out = torch.empty(B, H * D, dtype=q.dtype, device=q.device) if out is None else out
+    Smax = kcache.shape[1]
+    splits = int(L.lib().mh_attn_decode_splits(i32(B), i32(H), i32(Smax)))
+    ws = torch.empty(B * H * splits * (D + 2), dtype=torch.float32, device=q.device) if (splits > 1 and split_kv) else None
+    L.check(L.lib().mh_attn_decode(p(q), i64(q.stride(0)), p(kcache), p(vcache), p(out), p(lens), i32(B), i32(H), i32(D),
+                                   i32(Smax), p(ws), i32(dt_of(q)), _stream()), "mh_attn_decode")
+    return out
+
+
 _splitk_ws = {}
 
 

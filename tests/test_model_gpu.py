@@ -256,3 +256,47 @@ def test_frozen_tower_and_state_dict_keys():
         if "vision_tower" in k:
             assert p.grad is None
     assert model.lm_head.weight.grad is not None and float(model.lm_head.weight.grad.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["tiny_1img", "tiny_padbatch"])
+def test_kv_cache_decode_matches_full_recompute_and_oracle(name, dtype):
+    """generate() with a KV cache (prefill + one HBM-bound decode step per token) against (a) the same model decoding by
+    full-sequence recompute and (b) the fp32 CPU oracle run on the extended sequence, teacher-forced on the same tokens:
+    the logits that pick every new token must agree (tolerance of the dtype), for a single prompt with an image and for
+    a right-padded batch whose rows continue from their own lengths."""
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+
+    tol = TOL[dtype]["logits"] * 2
+    cfg, batch = C.get_case(name)
+    model = _build(cfg, dtype)
+    dev_b = _to_dev(batch)
+    ids, am, images = dev_b["input_ids"], dev_b["attention_mask"], dev_b["images"]
+    n_new = 6
+    logits, cache = model.engine.prefill(ids, am, images, n_new)
+    lens = am.to(torch.bool).sum(dim=1)
+    B = ids.shape[0]
+    P = R.make_params(cfg, seed=0, requires_grad=False)
+    cur_ids = [ids[b, :int(lens[b])].cpu() for b in range(B)]
+    for step in range(n_new):
+        nxt = logits.argmax(dim=-1)
+        for b in range(B):
+            # oracle: full forward of this row's sequence so far (no padding), last-position logits
+            with torch.no_grad():
+                ref = R.forward(P, cfg, cur_ids[b][None], torch.ones(1, len(cur_ids[b]), dtype=torch.bool), None,
+                                [batch["images"][b]])[1][0, -1]
+            got = logits[b].float().cpu()
+            assert float((got - ref).abs().max() / ref.abs().max()) < tol, (name, step, b)
+            cur_ids[b] = torch.cat([cur_ids[b], nxt[b:b + 1].cpu()])
+        if step + 1 < n_new:
+            logits = model.engine.decode_step(nxt, cache)
+    assert torch.equal(cache.lens.cpu(), (lens + n_new - 1).to(torch.int32).cpu())
+    # the public surface: cached and recompute decoding agree token for token (batch 1: no padding involved)
+    if B == 1:
+        a = model.generate(ids, images=images, max_new_tokens=n_new, use_cache=True, eos_token_id=-1)
+        b_ = model.generate(ids, images=images, max_new_tokens=n_new, use_cache=False, eos_token_id=-1)
+        assert a.shape == (1, ids.shape[1] + n_new)
+        assert torch.equal(a[:, :ids.shape[1]], ids)
+        # identical unless two candidates are within rounding of each other; require >= n_new-1 agreeing tokens
+        assert int((a == b_).sum()) >= a.numel() - 1

@@ -455,3 +455,58 @@ def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
         assert torch.equal(ops.gemm_nt(a, b, out_f32=True), o32) or relerr(ops.gemm_nt(a, b, out_f32=True), o32) < 1e-5
     finally:
         ops.gemm_force_kernel(0)
+
+
+# ---- KV-cache decode kernels ---------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4096), (3, 515, 264), (5, 32003, 256), (11, 1024, 11008)])
+def test_gemv_small_m(ops, dtype, M, N, K):
+    x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    resid = rnd(M, N, dtype=dtype, seed=2)
+    ref = x.float() @ w.float().t()
+    assert relerr(ops.gemv(x, w), ref) < 3 * EPS16[dtype]
+    assert relerr(ops.gemv(x, w, resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
+    assert relerr(ops.gemv(x, w, out_f32=True), ref) < 1e-5
+    assert torch.equal(ops.gemv(x, w), ops.gemv(x, w))
+    # against the MFMA GEMM on the same operands (the prefill path): same values up to the summation order
+    if K % 64 == 0:
+        assert relerr(ops.gemv(x, w, out_f32=True), ops.gemm_nt(x, w, out_f32=True)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,D,Smax,lens", [(2, 2, 128, 40, [17, 40]), (3, 4, 64, 700, [1, 333, 700]), (1, 32, 128, 4200, [4100])])
+def test_decode_rope_append_and_attention(ops, dtype, B, H, D, Smax, lens):
+    """One decode step against a torch fp32 restatement of HF LlamaAttention with a KV cache: rotate-half RoPE at each
+    sequence's own position, append, softmax(q K^T / sqrt(D)) V over the valid keys."""
+    d = H * D
+    kc, vc = rnd(B, Smax, d, dtype=dtype, seed=3), rnd(B, Smax, d, dtype=dtype, seed=4)
+    qkv = rnd(B, 3 * d, dtype=dtype, seed=5)
+    pos = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=dev())   # the new token's position
+    tab = ops.rope_table(Smax, D, 10000.0, dev())
+    kc0, vc0, qkv0 = kc.clone(), vc.clone(), qkv.clone()
+    ops.decode_rope_append(qkv, tab, pos, kc, vc, H, D)
+    # reference rotation
+    def rot(x, p):  # x [H, D] fp32
+        cos, sin = tab[p, :, 0], tab[p, :, 1]
+        lo, hi = x[:, :D // 2], x[:, D // 2:]
+        return torch.cat([lo * cos - hi * sin, hi * cos + lo * sin], dim=1)
+    for b in range(B):
+        p_ = int(pos[b])
+        qr = rot(qkv0[b, :d].float().view(H, D), p_)
+        kr = rot(qkv0[b, d:2 * d].float().view(H, D), p_)
+        assert relerr(qkv[b, :d].float().view(H, D), qr) < 2 * EPS16[dtype]
+        assert relerr(kc[b, p_].float().view(H, D), kr) < 2 * EPS16[dtype]
+        assert torch.equal(vc[b, p_], qkv0[b, 2 * d:])
+        keep = torch.ones(Smax, dtype=torch.bool, device=dev()); keep[p_] = False
+        assert torch.equal(kc[b][keep], kc0[b][keep]) and torch.equal(vc[b][keep], vc0[b][keep])
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev())
+    o = ops.attn_decode(qkv[:, :d], kc, vc, lens_t, H, D)
+    o1 = ops.attn_decode(qkv[:, :d], kc, vc, lens_t, H, D, split_kv=False)  # one block per (b, h)
+    assert relerr(o1, o.float()) < 2 * EPS16[dtype]
+    for b in range(B):
+        L_ = lens[b]
+        qh = qkv[b, :d].float().view(H, 1, D)
+        kh = kc[b, :L_].float().view(L_, H, D).permute(1, 0, 2)
+        vh = vc[b, :L_].float().view(L_, H, D).permute(1, 0, 2)
+        ref = torch.softmax(qh @ kh.transpose(1, 2) / D ** 0.5, dim=-1) @ vh
+        assert relerr(o[b].float().view(H, 1, D), ref) < 3 * EPS16[dtype]

@@ -130,7 +130,11 @@ def main():
     n_img = sum(int(im.shape[0]) for im in batch["images"])
     dbatch = dict(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
                   labels=batch["labels"].to(dev), images=[im.to(dev) for im in batch["images"]])
-    opt = FusedAdamW(model.engine, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.0)
+    # the reference's recipe (pretrain.sh:23-29): --llrd, lr 5e-5, beta2 0.95, wd 0.05, cosine warm-up; HF's default
+    # max_grad_norm=1.0 clipping - all of it inside the timed step
+    from merlin_amd.optim import vit_lr_scale, cosine_with_warmup
+    opt = FusedAdamW(model.engine, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
+    it = [0]
     sync = GradSync(model.engine) if world > 1 else None
 
     def step():
@@ -139,7 +143,9 @@ def main():
                 return model(**dbatch).loss
         out = model(**dbatch)
         out.loss.backward()
-        opt.step(grad_scale=(sync.grad_scale if sync else 1.0))
+        # (GradSync joins the communication stream at the end of backward: the clip sees the all-reduced gradients)
+        opt.step(grad_scale=(sync.grad_scale if sync else 1.0), max_grad_norm=1.0, lr_mult=cosine_with_warmup(it[0] + 10, 1000, 0.01))
+        it[0] += 1
         opt.zero_grad()
         return out.loss
 

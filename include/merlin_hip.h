@@ -222,6 +222,12 @@ int mh_ce_bwd(const float* logits, int64_t ldl, const int64_t* labels, const flo
 /* p, g are `dt`; m, v fp32.  Decoupled weight decay, bias-corrected; gscale multiplies g (1/world, clip). */
 int mh_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float wd, int step, float gscale, int dt, void* stream);
+/* Same update with an extra DEVICE-side gradient factor (gscale * *gscale_dev): global-norm clipping without a host
+ * round trip.  mh_clip_scale: out2[0] = min(1, max_norm / (sqrt(*sumsq) * |gscale| + 1e-6)), out2[1] = that norm
+ * (torch.nn.utils.clip_grad_norm_ as HF Trainer applies it with --max_grad_norm; trainer.py:45-74 builds the optimizer). */
+int mh_adamw_clip(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float wd, int step, float gscale, const float* gscale_dev, int dt, void* stream);
+int mh_clip_scale(const float* sumsq, float gscale, float max_norm, float* out2, void* stream);
 /* out[0] += sum(g^2) over n elements (fp32 atomic; zero it first) */
 int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream);
 

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void vit_assemble_k(const uint16_t* __restrict
 template <int DT>
 __global__ __launch_bounds__(256) void adamw_k(uint16_t* __restrict__ p, const uint16_t* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                               float wd, float bc1, float bc2, float gscale) {
+                                               float wd, float bc1, float bc2, float gscale, const float* __restrict__ gscale_dev) {
+  if (gscale_dev) gscale *= *gscale_dev;  // device-side factor (gradient clipping): no host round trip
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = ld16<DT>(g[i]) * gscale;
     float pi = ld16<DT>(p[i]);
@@ -302,7 +303,27 @@ extern "C" int mh_adamw(void* p, const void* g, float* m, float* v, int64_t n, f
                         float wd, int step, float gscale, int dt, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) return MH_ERR_ARG;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  DISPATCH16(dt, adamw_k, grid_for(n), (uint16_t*)p, (const uint16_t*)g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+  DISPATCH16(dt, adamw_k, grid_for(n), (uint16_t*)p, (const uint16_t*)g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, (const float*)nullptr);
+  MH_LAUNCH_CHECK();
+}
+extern "C" int mh_adamw_clip(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float wd, int step, float gscale, const float* gscale_dev, int dt, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return MH_ERR_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  DISPATCH16(dt, adamw_k, grid_for(n), (uint16_t*)p, (const uint16_t*)g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gscale_dev);
+  MH_LAUNCH_CHECK();
+}
+namespace {
+__global__ void clip_scale_k(const float* __restrict__ sumsq, float gscale, float max_norm, float* __restrict__ out) {
+  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1; total_norm of the SCALED gradients
+  const float norm = sqrtf(sumsq[0]) * fabsf(gscale);
+  out[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  out[1] = norm;
+}
+}  // namespace
+extern "C" int mh_clip_scale(const float* sumsq, float gscale, float max_norm, float* out2, void* stream) {
+  if (!sumsq || !out2 || max_norm <= 0.f) return MH_ERR_ARG;
+  hipLaunchKernelGGL(clip_scale_k, dim3(1), dim3(1), 0, as_stream(stream), sumsq, gscale, max_norm, out2);
   MH_LAUNCH_CHECK();
 }
 extern "C" int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream) {

@@ -455,6 +455,15 @@ def adamw_(param, grad, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
                              i32(step), f32(gscale), i32(dt_of(param)), _stream()), "mh_adamw")
 
 
+def adamw_clip_(param, grad, m, v, lr, beta1, beta2, eps, wd, step, gscale, gscale_dev):
+    L.check(L.lib().mh_adamw_clip(p(param), p(grad), p(m), p(v), i64(param.numel()), f32(lr), f32(beta1), f32(beta2), f32(eps), f32(wd),
+                                  i32(step), f32(gscale), p(gscale_dev), i32(dt_of(param)), _stream()), "mh_adamw_clip")
+
+
+def clip_scale(sumsq_t, gscale, max_norm, out2):
+    L.check(L.lib().mh_clip_scale(p(sumsq_t), f32(gscale), f32(max_norm), p(out2), _stream()), "mh_clip_scale")
+
+
 def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
 

@@ -5,9 +5,72 @@ One `mh_adamw` launch per run of adjacent parameters sharing (lr scale, weight d
 per layer instead of one per tensor.  fp32 moments live in two flat buffers shaped like the arena."""
 from __future__ import annotations
 
+import math
+import re
+
 import torch
 
 from . import ops as O
+
+
+# ---- layer-wise learning-rate decay (mmgpt/utils/llrd_utils.py:4-23), selected by --llrd / --llm_llrd (trainer.py:56-61) ----
+def vit_lr_scale(name: str) -> float:
+    """CLIP tower: 0.9 ** (22 - layer) for encoder layers, 0.1 for the rest of the vision model, 1 elsewhere."""
+    if "vision_model.encoder.layers" in name:
+        layer = int(re.findall(r"layers\.(\d+)\.", name)[0])
+        return 0.9 ** (23 - layer - 1)
+    if "vision_model" in name:
+        return 0.1
+    return 1
+
+
+def llm_lr_scale(name: str) -> float:
+    """Decoder: 0.931 ** (31 - layer) for `model.layers.N.`, 1 elsewhere."""
+    if "model.layers" in name:
+        layer = int(re.findall(r"layers\.(\d+)\.", name)[0])
+        return 0.931 ** (32 - layer - 1)
+    return 1
+
+
+def param_groups(named_parameters, lr, weight_decay, lr_scale_fn=None):
+    """The reference's grouping (llrd_utils.py:26-79): trainable parameters split by (decayed or not: biases and 1-D
+    tensors are not) x (lr multiplier), in the reference's group order.  Returns a list of dicts
+    {"names": [...], "weight_decay": wd, "lr": lr * mult}."""
+    wd_plain, wd_scaled, nowd_plain, nowd_scaled = [], {}, [], {}
+    for name, prm in named_parameters:
+        if not prm.requires_grad:
+            continue
+        no_wd = name.endswith(".bias") or prm.dim() == 1
+        mult = lr_scale_fn(name) if lr_scale_fn is not None else 1
+        scaled = mult != 1
+        if not no_wd and not scaled:
+            wd_plain.append(name)
+        elif not no_wd:
+            wd_scaled.setdefault(mult, []).append(name)
+        elif not scaled:
+            nowd_plain.append(name)
+        else:
+            nowd_scaled.setdefault(mult, []).append(name)
+    groups = []
+    if wd_plain:
+        groups.append({"names": wd_plain, "weight_decay": weight_decay, "lr": lr})
+    for mult, names in wd_scaled.items():
+        groups.append({"names": names, "weight_decay": weight_decay, "lr": lr * mult})
+    if nowd_plain:
+        groups.append({"names": nowd_plain, "weight_decay": 0.0, "lr": lr})
+    for mult, names in nowd_scaled.items():
+        groups.append({"names": names, "weight_decay": 0.0, "lr": lr * mult})
+    return groups
+
+
+def cosine_with_warmup(step: int, total_steps: int, warmup_ratio: float = 0.0, num_cycles: float = 0.5) -> float:
+    """lr multiplier of HF's `cosine` scheduler as the reference launches it (pretrain.sh:28-29: --warmup_ratio 0.01
+    --lr_scheduler_type cosine): linear warm-up over ceil(total * ratio) steps, then half a cosine to zero."""
+    warmup = math.ceil(total_steps * warmup_ratio)
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    progress = float(step - warmup) / float(max(1, total_steps - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * progress)))
 
 
 class FusedAdamW:
@@ -19,6 +82,7 @@ class FusedAdamW:
         self.m = self.v = None
         self._runs = None
         self._flat_id = None
+        self._clip = None
 
     def _build(self):
         A = self.engine.ensure_arena()
@@ -43,15 +107,32 @@ class FusedAdamW:
         return A
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, max_grad_norm: float = None, lr_mult: float = 1.0):
+        """One AdamW update.  grad_scale folds 1/world_size (and loss scaling) into the kernel; max_grad_norm clips the
+        global gradient norm like HF Trainer (--max_grad_norm, default 1.0) with the coefficient computed and applied
+        on the device; lr_mult is the scheduler's multiplier for this step (cosine_with_warmup)."""
         A = self._build()
         if A.gflat is None:
             return
         self.step_count += 1
         b1, b2 = self.betas
+        clip = None
+        if max_grad_norm is not None and max_grad_norm > 0:
+            if self._clip is None or self._clip.device != A.flat.device:
+                self._clip = torch.zeros(2, dtype=torch.float32, device=A.flat.device)
+            O.clip_scale(self.grad_norm_sq(), grad_scale, max_grad_norm, self._clip)
+            clip = self._clip
         for off, num, sc, wd in self._runs:
-            O.adamw_(A.flat[off: off + num], A.gflat[off: off + num], self.m[off: off + num], self.v[off: off + num],
-                     self.lr * sc, b1, b2, self.eps, wd, self.step_count, grad_scale)
+            args = (A.flat[off: off + num], A.gflat[off: off + num], self.m[off: off + num], self.v[off: off + num],
+                    self.lr * sc * lr_mult, b1, b2, self.eps, wd, self.step_count, grad_scale)
+            if clip is None:
+                O.adamw_(*args)
+            else:
+                O.adamw_clip_(*args, clip)
+
+    def last_grad_norm(self):
+        """Total gradient norm seen by the last clipped step (device scalar; what HF logs as grad_norm)."""
+        return None if self._clip is None else self._clip[1]
 
     def zero_grad(self, set_to_none=True):
         A = self.engine.arena
@@ -60,9 +141,13 @@ class FusedAdamW:
         for p in A.params.values():
             p.grad = None
 
-    def grad_norm(self):
-        """Global L2 norm of the gradient arena (device scalar tensor)."""
+    def grad_norm_sq(self):
+        """Sum of squares of the gradient arena (device scalar tensor; frozen parameters hold zeros)."""
         A = self.engine.arena
         out = torch.zeros(1, dtype=torch.float32, device=A.flat.device)
         O.sumsq(A.gflat, out)
         return out
+
+    def grad_norm(self):
+        """Global L2 norm of the gradient arena (device scalar tensor)."""
+        return self.grad_norm_sq().sqrt()

@@ -77,3 +77,18 @@ def save_state_dict(model, path, max_shard_numel=2_500_000_000):
         torch.save(sh, os.path.join(path, fn))
         wm.update({k: fn for k in sh})
     json.dump({"metadata": {}, "weight_map": wm}, open(os.path.join(path, "pytorch_model.bin.index.json"), "w"))
+
+
+def interpolate_pos_embed(pos_embed: torch.Tensor, factor: int = 2, extra_tokens: int = 1) -> torch.Tensor:
+    """Resize a CLIP position-embedding table [extra + g*g, d] to a (factor*g)^2 grid: bicubic, align_corners=True, the
+    class-token row(s) kept (mmgpt/utils/interpolate_model.py:12-30, used to take the 224-px... 336-px tower to the
+    released 448-px checkpoint).  Returns the new table; the caller also resets `position_ids` to arange(new_len)."""
+    import torch.nn.functional as F
+
+    g = round((pos_embed.shape[0] - extra_tokens) ** 0.5)
+    assert g * g + extra_tokens == pos_embed.shape[0], "not a square grid"
+    tok, img = pos_embed[:extra_tokens], pos_embed[extra_tokens:]
+    img = img.reshape(1, g, g, -1).permute(0, 3, 1, 2)
+    img = F.interpolate(img.float(), size=(g * factor, g * factor), mode="bicubic", align_corners=True).to(pos_embed.dtype)
+    img = img.permute(0, 2, 3, 1).reshape(g * factor * g * factor, -1)
+    return torch.cat([tok, img], dim=0)

@@ -668,8 +668,28 @@ class HipEngine:
         Vpad = _ru(V, 64)
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
         logits = O.gemv(hn, wlm, out_f32=True, n=V)
-        cache.lens = lens1
+        cache.lens.add_(1)  # in place (after every kernel that read it as `pos`): the captured graph sees the same buffer
         return logits
+
+    def capture_decode_graph(self, cache):
+        """Capture one decode step (≈300 launches) into a HIP graph bound to `cache`: returns (graph, token buffer int64 [B],
+        logits buffer fp32 [B, V]).  Positions live in cache.lens on the device and advance inside the graph, so every
+        replay is the next token.  One eager warm-up step runs first (function attributes, symbol look-ups and allocator
+        warm-up must not happen during capture); it writes only the cache rows the first real step rewrites."""
+        dev = self.arena.flat.device
+        tok = torch.zeros(cache.B, dtype=torch.int64, device=dev)
+        keep = cache.lens.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.decode_step(tok, cache)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        cache.lens.copy_(keep)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            logits = self.decode_step(tok, cache)
+        cache.lens.copy_(keep)  # capture does not execute, but keep the invariant explicit
+        return g, tok, logits
 
     # standalone sub-module calls (reference module surface; not used by the fused forward)
     def tower_forward_public(self, images):

@@ -295,6 +295,8 @@ def test_kv_cache_decode_matches_full_recompute_and_oracle(name, dtype):
     # the public surface: cached and recompute decoding agree token for token (batch 1: no padding involved)
     if B == 1:
         a = model.generate(ids, images=images, max_new_tokens=n_new, use_cache=True, eos_token_id=-1)
+        a_eager = model.generate(ids, images=images, max_new_tokens=n_new, use_cache=True, use_graph=False, eos_token_id=-1)
+        assert torch.equal(a, a_eager), "graph replay and eager decode must be bit-identical"
         b_ = model.generate(ids, images=images, max_new_tokens=n_new, use_cache=False, eos_token_id=-1)
         assert a.shape == (1, ids.shape[1] + n_new)
         assert torch.equal(a[:, :ids.shape[1]], ids)

@@ -9,7 +9,7 @@ from merlin_amd import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-NEW = 64
+NEW = 160
 dev = torch.device("cuda:0")
 llama = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
              rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192)
@@ -36,4 +36,17 @@ with torch.no_grad():
     wbytes = sum(p.numel() for n_, p in model.named_parameters() if n_.startswith("model.layers") or n_.startswith("lm_head") or n_ == "model.norm.weight") * 2
     cbytes = 2 * 32 * B * (S + 20) * 4096 * 2
     print(json.dumps({"decode": "eager", "B": B, "context": S, "ms_per_step": round(ms, 3), "tokens_per_s": round(B * 1e3 / ms, 1),
+                      "hbm_gb_per_step": round((wbytes + cbytes) / 1e9, 2), "hbm_tb_s": round((wbytes + cbytes) / ms / 1e9, 2)}), flush=True)
+    # the same step as one replayed HIP graph
+    g, gtok, glog = model.engine.capture_decode_graph(cache)
+    gtok.copy_(tok)
+    for _ in range(3):
+        g.replay(); gtok.copy_(glog.argmax(-1))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        g.replay(); gtok.copy_(glog.argmax(-1))
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print(json.dumps({"decode": "hip-graph", "B": B, "context": S, "ms_per_step": round(ms, 3), "tokens_per_s": round(B * 1e3 / ms, 1),
                       "hbm_gb_per_step": round((wbytes + cbytes) / 1e9, 2), "hbm_tb_s": round((wbytes + cbytes) / ms / 1e9, 2)}), flush=True)

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4(GemmArgs g) {
   // MFMAs: every fragment read, M0 write and copy below is placed behind its own MFMA.
   auto mfma_slot = [&](auto SET, auto SL) {
     constexpr int s = decltype(SET)::value, sl = decltype(SL)::value;
-    mfma_acc<DT>(acc[sl / 8][sl % 8], bf[s][sl % 8], af[s][sl / 8]);
+    mfma_acc<DT>(acc[sl % 8][sl / 8], bf[s][sl / 8], af[s][sl % 8]);  // srcA (B fragment) fixed for 8 consecutive MFMAs
   };
   // copy schedule of K-tile t+2 (-> buffer t&1), one M0 write + one copy per 6 MFMA slots so that the address
   // pipe sees a steady ~40 B/clk instead of a 128 B/clk burst: copies 0..6 at phase-E slots 24+6c, copies 7..15 at

@@ -4,12 +4,12 @@ from merlin_amd import ops as O
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_ops import timeit
 dev = torch.device("cuda:0")
-M, N = 32768, 4096
+M, N = 32768, (int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
 tiles = (M // 256) * (N // 256)
 rounds = tiles / 256
 for which in (256, 4):
     ts = []
-    for K in (1024, 2048, 4096, 8192, 16384):
+    for K in (1024, 2048, 4096, 8192):
         a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         if which == "lib":

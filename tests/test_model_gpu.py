@@ -345,3 +345,62 @@ def test_fused_adamw_llrd_clip_schedule_vs_torch_adamw():
         assert float(err) <= float(ulp) * 1.01, (n, float(err), float(ulp))
         worst = max(worst, float(err))
     assert worst > 0.0  # (bf16 storage: the fp32 result is not reproduced exactly, only to rounding)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ragged_batch_equals_per_sequence_runs_at_real_widths(dtype):
+    """The ragged variant of cfg 3 (lengths 4096, 3900, ... exercise the key-padding branch,
+    llama_flash_attn_monkey_patch.py:87-102) as a size-independent property at the real head width (d 4096, 32 heads of
+    128, 2 layers): a right-padded batch must give, at every valid position, the logits of the same sequence run alone
+    without padding, and the loss must be the token-weighted combination of the single-sequence losses; gradients of the
+    padded run must not depend on what the pad positions hold."""
+    from merlin_amd import synth
+    from oracle import cases as C
+
+    cfg = C.medium_cfg()
+    S, lens = 768, [768, 701, 130]
+    P_img = cfg.num_patches
+    samples = []
+    g = torch.Generator().manual_seed(3)
+    for b, L_ in enumerate(lens):
+        one = synth.interpair_batch(B=1, S=L_, frames=1, base_vocab=cfg.vocab_size - 3, P=P_img, image_size=cfg.v_image_size,
+                                    rank=b) if L_ > P_img + 16 else None
+        if one is None:  # a text-only row (with the reference's zeros image)
+            ids = torch.randint(3, cfg.vocab_size - 3, (1, L_), generator=g)
+            ids[0, 0] = 1
+            lab = ids.clone(); lab[0, : L_ // 2] = -100
+            one = dict(input_ids=ids, labels=lab, attention_mask=torch.ones(1, L_, dtype=torch.bool), images=[torch.zeros(1, 3, cfg.v_image_size, cfg.v_image_size)])
+        samples.append(one)
+    pad = lambda t, v: torch.cat([t, torch.full((1, S - t.shape[1]), v, dtype=t.dtype)], dim=1)
+    batch = dict(input_ids=torch.cat([pad(s["input_ids"], 0) for s in samples]), labels=torch.cat([pad(s["labels"], -100) for s in samples]),
+                 attention_mask=torch.cat([pad(s["attention_mask"].to(torch.bool), False) for s in samples]), images=[s["images"][0] for s in samples])
+    model = _build(cfg, dtype)
+    out = model(**_to_dev(batch))
+    out.loss.backward()
+    g_pad = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    tol = TOL[dtype]["logits"]
+    num, den = 0.0, 0
+    for b, s in enumerate(samples):
+        o1 = model(**_to_dev(s))
+        L_ = lens[b]
+        ref = o1.logits[0].float()
+        got = out.logits[b, :L_].float()
+        assert float((got - ref).abs().max() / ref.abs().max()) < tol, b
+        n = int((s["labels"][0, 1:] != -100).sum())
+        num += float(o1.loss) * n
+        den += n
+    assert abs(float(out.loss) - num / den) / (num / den) < TOL[dtype]["loss"]
+    # pad contents are irrelevant: garbage ids in the pad region, same mask -> identical loss and gradients
+    junk = dict(batch)
+    ids2 = batch["input_ids"].clone()
+    for b, L_ in enumerate(lens):
+        ids2[b, L_:] = 7
+    junk["input_ids"] = ids2
+    out2 = model(**_to_dev(junk))
+    out2.loss.backward()
+    assert float(out2.loss) == float(out.loss)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g_pad[k]), k

@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2", "cfg3-ragged", "cfg5-bf16"],
+                    help="cfg3 = BASELINE metric config (default); cfg3-ragged = same with ragged lengths + key padding; "
+                         "cfg5-bf16 = cfg 5's S=8192 interleave shape with bf16 weights (the fp8 weight path is not built)")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recompute", action="store_true", help="recompute each layer's forward in backward (the reference's "
@@ -122,6 +124,14 @@ def main():
         B = args.batch or 8
         batch = synth.interpair_batch(B=B, S=4096, rank=rank)
         workload = f"interpair: B={B}/GPU x S=4096 (6 x 336px frames + trajectory text), ViT-L/14-336 + mlp projector + Llama-7B"
+    elif args.config == "cfg3-ragged":
+        B = args.batch or 8
+        batch = synth.interpair_batch(B=B, S=4096, rank=rank, ragged=True)
+        workload = f"interpair ragged: B={B}/GPU, lengths <= 4096 right-padded (key-padding branch), 6 frames, ViT-L/14-336 + mlp + Llama-7B"
+    elif args.config == "cfg5-bf16":
+        B = args.batch or 4
+        batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
+        workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
     else:
         B = 1
         batch = synth.single_image_batch()
@@ -166,16 +176,22 @@ def main():
     dt = time.perf_counter() - t0
     prof = O.profile_stop()
     loss_val = float(loss)
+    n_tok = int(batch["attention_mask"].sum())  # the metric counts sequence positions, padding excluded
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        c = torch.tensor([n_tok], device=dev, dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_tok_all = int(c)
+    else:
+        n_tok_all = n_tok
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
-    tokens = world * B * S
+    tokens = n_tok_all
     value = tokens / (dt / args.steps)
     fwd = algorithmic_flops_fwd(B, S, n_img)
     useful = fwd * (1.0 if args.fwd_only else 3.0)

@@ -26,15 +26,17 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
   else return __builtin_amdgcn_fdot2(__builtin_bit_cast(mh_h2, a), __builtin_bit_cast(mh_h2, b), c, false);
 }
 
-// ROWS weight rows per wave: an activation chunk (MM x 8 values) is loaded once and used against ROWS weight rows,
-// so for MM = 8 the L1 traffic of the activations drops from 8x to 2x the weight stream.
-template <int DT, int MM, int ROWS>
+// ROWS weight rows per wave, 4 waves per block.  LDSX: the block first stages a K-chunk of the MM activation rows in
+// LDS (MM x 4096 x 2 B = 64 KiB at MM = 8) and every wave reads it from there: without it each wave re-fetches all
+// activations through L1/L2 (8x the weight bytes at MM = 8; measured 1.9 TB/s of weights instead of 5).
+constexpr int GEMV_KC = 2048;  // 32 KiB at MM = 8: four blocks (16 waves) per CU keep enough weight loads in flight
+template <int DT, int MM, int ROWS, bool LDSX>
 __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
                                               int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
                                               int64_t ldr, int N, int K, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [MM][GEMV_KC] when LDSX
   const int lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
-  if (n0 >= N) return;
   float acc[ROWS][MM];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
@@ -43,24 +45,49 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   const uint16_t* wrow[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) wrow[r] = W + (int64_t)min(n0 + r, N - 1) * ldw;
-  for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    uint4 wv[ROWS];
+  for (int kc = 0; kc < K; kc += GEMV_KC) {
+    const int klen = min(GEMV_KC, K - kc);
+    if constexpr (LDSX) {
+      if (kc) __syncthreads();
+      for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
+        const int m = i / klen, k = i - m * klen;
+        *(uint4*)(xs + m * GEMV_KC + k) = *(const uint4*)(x + (int64_t)m * ldx + kc + k);
+      }
+      __syncthreads();
+    }
+    if (n0 < N) {
+      // two 512-element steps per iteration: 2 x ROWS weight loads in flight per lane before any is consumed
+      for (int k0 = lane * 8; k0 < klen; k0 += 1024) {
+        uint4 wv[2][ROWS];
+        const bool two = k0 + 512 < klen;
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) wv[r] = *(const uint4*)(wrow[r] + k0);
+        for (int r = 0; r < ROWS; ++r) wv[0][r] = *(const uint4*)(wrow[r] + kc + k0);
 #pragma unroll
-    for (int m = 0; m < MM; ++m) {
-      const uint4 xv = *(const uint4*)(x + (int64_t)m * ldx + k0);
+        for (int r = 0; r < ROWS; ++r) wv[1][r] = two ? *(const uint4*)(wrow[r] + kc + k0 + 512) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        float a = acc[r][m];
-        a = dot2_acc<DT>(wv[r].x, xv.x, a);
-        a = dot2_acc<DT>(wv[r].y, xv.y, a);
-        a = dot2_acc<DT>(wv[r].z, xv.z, a);
-        a = dot2_acc<DT>(wv[r].w, xv.w, a);
-        acc[r][m] = a;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int kk = k0 + h2 * 512;
+          if (h2 == 1 && !two) break;
+#pragma unroll
+          for (int m = 0; m < MM; ++m) {
+            uint4 xv;
+            if constexpr (LDSX) xv = *(const uint4*)(xs + m * GEMV_KC + kk);
+            else xv = *(const uint4*)(x + (int64_t)m * ldx + kc + kk);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+              float a = acc[r][m];
+              a = dot2_acc<DT>(wv[h2][r].x, xv.x, a);
+              a = dot2_acc<DT>(wv[h2][r].y, xv.y, a);
+              a = dot2_acc<DT>(wv[h2][r].z, xv.z, a);
+              a = dot2_acc<DT>(wv[h2][r].w, xv.w, a);
+              acc[r][m] = a;
+            }
+          }
+        }
       }
     }
   }
+  if (n0 >= N) return;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
@@ -237,19 +264,35 @@ extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, v
   if (!x || !W || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  const int rows = M >= 3 ? 4 : 2;  // weight rows per wave
+  // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
+  // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
+  const int rows = M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1));
   const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
   hipStream_t st = as_stream(stream);
-#define GO(DT_, MM_, R_)                                                                                                     \
-  hipLaunchKernelGGL((gemv_k<DT_, MM_, R_>), grid, block, 0, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
-                     (const uint16_t*)resid, ldr, N, K, out_f32)
+#define GO(DT_, MM_, R_, L_)                                                                                                      \
+  do {                                                                                                                             \
+    const size_t lds_ = L_ ? (size_t)MM_ * GEMV_KC * 2 : 0;                                                                        \
+    static bool attr_ = false;                                                                                                     \
+    if (L_ && !attr_) {                                                                                                            \
+      hipFuncSetAttribute((const void*)gemv_k<DT_, MM_, R_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);           \
+      attr_ = true;                                                                                                                \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
+                       (const uint16_t*)resid, ldr, N, K, out_f32);                                                               \
+  } while (0)
+#define GOR(DT_, MM_)                                                                  \
+  do {                                                                                 \
+    if (rows == 4) GO(DT_, MM_, 4, true); else if (rows == 2) GO(DT_, MM_, 2, true); else GO(DT_, MM_, 1, true); \
+  } while (0)
 #define GOM(DT_)                                                                                                       \
   switch (M) {                                                                                                         \
-    case 1: GO(DT_, 1, 2); break; case 2: GO(DT_, 2, 2); break; case 3: GO(DT_, 3, 4); break; case 4: GO(DT_, 4, 4); break; \
-    case 5: GO(DT_, 5, 4); break; case 6: GO(DT_, 6, 4); break; case 7: GO(DT_, 7, 4); break; default: GO(DT_, 8, 4); break; \
+    case 1: GO(DT_, 1, 2, false); break; case 2: GO(DT_, 2, 2, false); break; case 3: GOR(DT_, 3); break;             \
+    case 4: GOR(DT_, 4); break; case 5: GOR(DT_, 5); break; case 6: GOR(DT_, 6); break;                               \
+    case 7: GOR(DT_, 7); break; default: GOR(DT_, 8); break;                                                           \
   }
-  if (dt == MH_BF16) { GOM(MH_BF16) } else { GOM(MH_F16) }
+  if (dt == MH_BF16) { GOM(MH_BF16); } else { GOM(MH_F16); }
 #undef GOM
+#undef GOR
 #undef GO
   MH_LAUNCH_CHECK();
 }

@@ -1,0 +1,39 @@
+"""Reduce the rocprofv3 --pmc passes of tools/pmc_step_traffic.sh to per-launch L2<->fabric traffic of the GEMM kernels."""
+import glob, json, sqlite3, sys, collections
+
+
+def load(d):
+    out = collections.defaultdict(float)
+    n = collections.Counter()
+    for db in glob.glob(d + "/**/*.db", recursive=True):
+        c = sqlite3.connect(db)
+        cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
+        ix = {k: i for i, k in enumerate(cols)}
+        name_col = "kernel_name" if "kernel_name" in ix else "name"
+        for r in c.execute("select * from counters_collection"):
+            if "gemm_nt" not in str(r[ix[name_col]]):
+                continue
+            out[r[ix["counter_name"]]] += float(r[ix["value"]])
+            n[r[ix["counter_name"]]] += 1
+    return out, n
+
+
+a, na = load(sys.argv[1]); b, nb = load(sys.argv[2]); c, nc = load(sys.argv[3]) if len(sys.argv) > 3 else ({}, {})
+launches = max(na.values()) if na else 0
+rd, rd32 = a.get("TCC_EA0_RDREQ_sum", 0.0), a.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+if c.get("TCC_EA0_RDREQ_128B_sum") or c.get("TCC_EA0_RDREQ_64B_sum"):
+    r128, r64 = c.get("TCC_EA0_RDREQ_128B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0)
+    read_bytes = 32 * rd32 + 64 * r64 + 128 * r128
+    how = "reads = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B (exact request sizes)"
+else:
+    read_bytes = 32 * rd32 + 128 * (rd - rd32)
+    how = "reads = 32*RDREQ_32B + 128*(RDREQ - RDREQ_32B): wide coalesced reads are 128-B requests on gfx950 (the guide's 2x FETCH_SIZE correction)"
+wr, wr64 = b.get("TCC_EA0_WRREQ_sum", 0.0), b.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+write_bytes = 64 * wr64 + 32 * (wr - wr64)
+hit, miss = a.get("TCC_HIT_sum", 0.0), a.get("TCC_MISS_sum", 0.0)
+L = max(1, launches)
+print(json.dumps({"kernel": "gemm_nt_256 + gemm_nt_128 (all launches of one cfg-3 training step)", "launches": launches,
+                  "fabric_read_bytes_per_launch": read_bytes / L, "fabric_write_bytes_per_launch": write_bytes / L,
+                  "traffic_bytes_per_launch": (read_bytes + write_bytes) / L, "l2_hit_rate": hit / max(1.0, hit + miss),
+                  "method": "rocprofv3 --pmc, separate passes (tools/pmc_step_traffic.sh); " + how + "; writes = 64*WRREQ_64B + 32*(WRREQ-WRREQ_64B); "
+                            "counters sit on the L2<->fabric (EA) side, i.e. Infinity-Cache hits are included"}, indent=1))

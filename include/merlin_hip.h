@@ -78,6 +78,12 @@ int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t l
  * partials (fixed order: deterministic) into C (`dt` or fp32, optionally += C).  mh_gemm_splitk_max returns the
  * split count the library would use for a shape (1 = not worth splitting).  With both operands K-strided, K may be
  * any positive value: rows k >= K of the last K-tile are read as zeros. */
+/* C = A B^T (16-bit, K-contiguous operands) with RoPE fused into the epilogue: columns [0, rope_cols) of C are heads of D
+ * channels rotated (rotate-half) at position row % S with the mh_rope_table layout - the fused q|k|v projection of
+ * llama_flash_attn_monkey_patch.py:35-59 in one launch, bit-identical to mh_gemm_nt followed by mh_rope_qk.
+ * D in {64, 128}; rope_cols % D == 0; N % 8 == 0; 16-byte aligned C rows. */
+int mh_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int dt,
+                    const float* cos_sin, int S, int D, int rope_cols, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
@@ -142,7 +148,7 @@ int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
  * come from LDS transpose-reads).  `delta`: ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats. */
 int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                  const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
-                 void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
+                 void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt, void* stream);
 /* Backward: `delta` is a ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats (rowsum(dO*O), then lse*log2e).
  * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
  * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */

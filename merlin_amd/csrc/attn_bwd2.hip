@@ -32,6 +32,7 @@ struct Bwd2Args {
   int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int B, S, H, S_pad;
   float scale, scale_log2, inv_scale;
+  const float2* rope;  // optional: inverse RoPE (rotate-half) of dQ and dK rows at their sequence position, fused into the epilogues
 };
 
 template <int N>
@@ -102,6 +103,30 @@ __device__ __forceinline__ void stream_tr_frags(const unsigned* addr, F&& consum
       lds_read64_tr<(R0 + (g % 2) * 16 + 8) * RB>(w[2 * (f % W) + 1], addr[2 * (g / 2) + 1]);
     }
   });
+}
+
+// Inverse RoPE of one gradient row held in the epilogue layout (lane: channels 32*i + 8*g + 4*hi + e of its row): the
+// partner of channel d < D/2 is d + D/2 = accumulator block i + DBLK/2 of the SAME lane, so the rotation is in registers.
+// tab points at the (cos, sin) row of this lane's sequence position.  Gradient of y = rope(x): x_bar = rope^T(y_bar) =
+// rotation by -theta.
+template <int D>
+__device__ __forceinline__ void unrope_rows(f32x16_t (&v)[D / 32], const float2* tab, int hi) {
+  constexpr int HB = D / 64;  // accumulator blocks per half head
+#pragma unroll
+  for (int i = 0; i < HB; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4* t4 = (const float4*)(tab + 32 * i + 8 * g + 4 * hi);
+      const float4 t01 = t4[0], t23 = t4[1];  // (c0, s0, c1, s1), (c2, s2, c3, s3)
+      const float cs[4] = {t01.x, t01.z, t23.x, t23.z}, sn[4] = {t01.y, t01.w, t23.y, t23.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo, hi_;
+        rope_rot(v[i][4 * g + e], v[i + HB][4 * g + e], cs[e], -sn[e], lo, hi_);
+        v[i][4 * g + e] = lo;
+        v[i + HB][4 * g + e] = hi_;
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -227,12 +252,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
 #pragma unroll
     for (int i = 0; i < DBLK; ++i)
 #pragma unroll
+      for (int r = 0; r < 16; ++r) dqacc[i][r] *= a.scale;
+    if (a.rope && valid) unrope_rows<D>(dqacc, a.rope + (int64_t)qrow * (D / 2), hi);
+#pragma unroll
+    for (int i = 0; i < DBLK; ++i)
+#pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * i + 8 * g + 4 * hi;
         uint2 w = make_uint2(0, 0);
         if (valid)
-          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0] * a.scale, dqacc[i][4 * g + 1] * a.scale),
-                         pack2<DT>(dqacc[i][4 * g + 2] * a.scale, dqacc[i][4 * g + 3] * a.scale));
+          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0], dqacc[i][4 * g + 1]), pack2<DT>(dqacc[i][4 * g + 2], dqacc[i][4 * g + 3]));
         *(uint2*)(dqp + d) = w;
       }
   }
@@ -387,7 +416,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
 
   if (kvrow < S) {
     const bool valid = kvrow < len;
-    const float osc = DO_DK ? a.scale : 1.0f;
+    if constexpr (DO_DK) {
+#pragma unroll
+      for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] *= a.scale;
+      if (a.rope && valid) unrope_rows<D>(acc, a.rope + (int64_t)kvrow * (D / 2), hi);
+    }
 #pragma unroll
     for (int i = 0; i < DBLK; ++i)
 #pragma unroll
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
         const int d = 32 * i + 8 * g + 4 * hi;
         uint2 w = make_uint2(0, 0);
         if (valid)
-          w = make_uint2(pack2<DT>(acc[i][4 * g + 0] * osc, acc[i][4 * g + 1] * osc), pack2<DT>(acc[i][4 * g + 2] * osc, acc[i][4 * g + 3] * osc));
+          w = make_uint2(pack2<DT>(acc[i][4 * g + 0], acc[i][4 * g + 1]), pack2<DT>(acc[i][4 * g + 2], acc[i][4 * g + 3]));
         *(uint2*)(outp + d) = w;
       }
   }
@@ -426,7 +461,7 @@ int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
 extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                             int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq,
                             void* dk, int64_t lddk, void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D,
-                            int causal, int dt, void* stream) {
+                            int causal, const float* rope_cos_sin, int dt, void* stream) {
   using namespace mhattn;
   if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 1) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
@@ -441,6 +476,7 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2 = a.scale * 1.4426950408889634f;
   a.inv_scale = sqrtf((float)D);
+  a.rope = (const float2*)rope_cos_sin;
   hipStream_t st = as_stream(stream);
 #define GO(DT_, D_, C_) return launch_bwd2<DT_, D_, C_>(a, st)
   if (dt == MH_BF16) {

@@ -136,10 +136,7 @@ __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv,
     unpack8<DT>(*(const uint4*)(base + half), hi);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float c = tb[k].x, s = tb[k].y;
-      const float a = lo[k], bb = hi[k];
-      lo[k] = a * c - bb * s;
-      hi[k] = bb * c + a * s;
+      rope_rot(lo[k], hi[k], tb[k].x, tb[k].y, lo[k], hi[k]);
     }
     const uint4 plo = pack8<DT>(lo), phi = pack8<DT>(hi);
     *(uint4*)base = plo;

@@ -144,9 +144,7 @@ __global__ __launch_bounds__(256) void rope_qk_k(uint16_t* __restrict__ qkv, con
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float c = tb[k].x, s = inverse ? -tb[k].y : tb[k].y;
-      const float a = lo[k], b = hi[k];
-      lo[k] = a * c - b * s;  // x*cos + rotate_half(x)*sin, rotate_half = (-x2, x1)
-      hi[k] = b * c + a * s;
+      rope_rot(lo[k], hi[k], c, s, lo[k], hi[k]);  // x*cos + rotate_half(x)*sin, rotate_half = (-x2, x1)
     }
     *(uint4*)base = pack8<DT>(lo);
     *(uint4*)(base + half) = pack8<DT>(hi);

@@ -186,9 +186,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
   }
 }
 
+struct RopeSpec { const float* tab = nullptr; int S = 0, D = 0, cols = 0; };
 static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                      int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
-                     int epilogue, int splits, int64_t c_split, void* stream);
+                     int epilogue, int splits, int64_t c_split, void* stream, RopeSpec rope = RopeSpec());
+
+extern "C" int mh_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                               int dt, const float* cos_sin, int S, int D, int rope_cols, void* stream) {
+  // staged-epilogue conditions + whole heads per 256-column tile
+  if (!cos_sin || S <= 0 || (D != 128 && D != 64) || rope_cols <= 0 || rope_cols > N || (rope_cols % D) || (N & 7) || (ldc & 7) ||
+      ((((uintptr_t)C) & 15u) != 0))
+    return MH_ERR_ARG;
+  RopeSpec r;
+  r.tab = cos_sin; r.S = S; r.D = D; r.cols = rope_cols;
+  return gemm_impl(A, lda, 0, B, ldb, 0, C, ldc, nullptr, nullptr, 0, M, N, K, dt, 0, 1, 0, stream, r);
+}
 
 extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                        int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
@@ -231,7 +243,7 @@ extern "C" int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const 
 
 static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                      int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
-                     int epilogue, int splits, int64_t c_split, void* stream) {
+                     int epilogue, int splits, int64_t c_split, void* stream, RopeSpec rope) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
   const bool both_ks = a_kstrided && b_kstrided;  // the only form whose K need not be a multiple of 64 (zero rows)
   if ((!both_ks && K % BK != 0) || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B)) return MH_ERR_ARG;
@@ -245,6 +257,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split;
+  g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   {
     static void* zp = nullptr;
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
@@ -265,17 +278,17 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
-  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1) {  // A/B arm: MFMA 32x32x16 fragments
+  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab) {  // A/B arm: MFMA 32x32x16 fragments
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
+  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
   }
-  if (big || a_kstrided || b_kstrided || splits > 1) {  // K-strided operands / split-K exist only in the 8-wave 256-tile kernel
+  if (big || a_kstrided || b_kstrided || splits > 1 || rope.tab) {  // K-strided operands / split-K / fused RoPE exist only in the 8-wave 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_256(g, dt, a_kstrided, b_kstrided, as_stream(stream));

@@ -297,6 +297,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     __syncthreads();
     const int ncol = n0 + (tid & 31) * 8;
     const bool n_ok = ncol < g.N;
+    if (g.rope_tab && ncol < g.rope_cols) {
+      // fused RoPE (llama_flash_attn_monkey_patch.py:56-59): the tile holds whole heads (256 % D == 0), so the thread
+      // that owns a low-half 8-channel chunk also reads its partner chunk D/2 channels later from the same LDS row and
+      // rotates the two ROUNDED 16-bit values exactly as the stand-alone mh_rope_qk does on the stored tensor.
+      const int hc = g.rope_D >> 4;            // chunks per half head
+      const int c = tid & 31;
+      if ((c % (2 * hc)) < hc) {
+        const int j0 = (c % hc) * 8;           // first rotary pair index of this chunk
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+          const int row = pass * 16 + (tid >> 5);
+          if (m0 + row >= g.M) continue;
+          float lo[8], hi[8];
+          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + c * 16), lo);
+          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (c + hc) * 16), hi);
+          const float2* tb = (const float2*)g.rope_tab + (int64_t)((m0 + row) % g.rope_S) * (g.rope_D >> 1) + j0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            rope_rot(lo[k], hi[k], tb[k].x, tb[k].y, lo[k], hi[k]);
+          }
+          uint16_t* dst = (uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc + ncol;
+          *(uint4*)dst = pack8<DT>(lo);
+          *(uint4*)(dst + (g.rope_D >> 1)) = pack8<DT>(hi);
+        }
+      }
+      return;
+    }
 #pragma unroll 4
     for (int pass = 0; pass < 16; ++pass) {
       const int row = pass * 16 + (tid >> 5);

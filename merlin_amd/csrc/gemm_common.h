@@ -15,6 +15,10 @@ struct GemmArgs {
   int splits;              // split-K: grid.y blocks share a tile, block y writes fp32 partials to C + y*c_split
   int64_t c_split;         // elements between the partial outputs of consecutive splits
   const uint16_t* zero_row;  // >= 1 KiB of zeros: source of K-strided rows k >= K in the last K-tile
+  // fused RoPE of the staged epilogue (qkv projection): columns [0, rope_cols) are heads of rope_D channels rotated
+  // at position (row % rope_S) with the (cos, sin) table rope_tab [pos][rope_D/2]; nullptr = off
+  const float* rope_tab;
+  int rope_S, rope_D, rope_cols;
 };
 
 constexpr int BK = 64;

@@ -65,6 +65,13 @@ template <int DT> __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// rotate-half RoPE of one (x[i], x[i + D/2]) pair; ONE definition with explicit fmas so that the stand-alone kernel, the
+// decode kernel and the GEMM-epilogue form round identically (inverse: pass -sin)
+__device__ __forceinline__ void rope_rot(float a, float b, float c, float s, float& lo, float& hi) {
+  lo = fmaf(a, c, -(b * s));
+  hi = fmaf(b, c, a * s);
+}
+
 // ---- MFMA wrappers ------------------------------------------------------------------------
 // 16x16x32: A lane l holds A[i=l&15][k=8*(l>>4)..+8]; B lane l holds B[k=8*(l>>4)..+8][j=l&15];
 // D lane l reg r holds D[i=4*(l>>4)+r][j=l&15].

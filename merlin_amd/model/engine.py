@@ -373,8 +373,7 @@ class HipEngine:
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         eps = cfg.rms_norm_eps
         h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-        qkv = O.gemm_nt(h1, W.wqkv)
-        O.rope_qk_(qkv, self.rope, S, H, D)
+        qkv = O.gemm_nt_rope(h1, W.wqkv, self.rope, S, H, D)  # q|k|v projection with RoPE in the GEMM epilogue
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         if kv_out is not None:  # prefill: rotated keys and values go to the decode cache [B, Smax, d]
             kv_out[0][:, :S].copy_(k.view(B, S, d))
@@ -417,8 +416,8 @@ class HipEngine:
             self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
-        O.rope_qk_(dqkv, self.rope, S, H, D, inverse=True)
+        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:],
+                    rope=self.rope)  # inverse RoPE of dq, dk fused into the kernels' epilogues
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
             self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)

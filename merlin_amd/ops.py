@@ -187,6 +187,18 @@ def wgrad_tn(dy, x, out, accum):
     return out
 
 
+def gemm_nt_rope(a, b, table, S, H, D, out=None):
+    """qkv = a @ b^T with RoPE applied to the q and k heads in the GEMM epilogue (b = fused [q; k; v] weight, 3*H*D rows)."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert N == 3 * H * D and b.shape[1] == K and a.dtype == b.dtype
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
+    with _timed("gemm_nt", 2.0 * M * N * K):
+        L.check(L.lib().mh_gemm_nt_rope(p(a), i64(_rowmajor(a)), p(b), i64(_rowmajor(b)), p(out), i64(_rowmajor(out)), i32(M), i32(N),
+                                        i32(K), i32(dt_of(a)), p(table), i32(S), i32(D), i32(2 * H * D), _stream()), "mh_gemm_nt_rope")
+    return out
+
+
 def transpose16(x, r_pad=None, out=None):
     """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
     R, Cc = x.shape
@@ -346,15 +358,16 @@ def attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=None, out=None, lse=None):
     return out, lse
 
 
-def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None):
-    """Backward without re-layout passes or workspace (transpose-read kernels)."""
+def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None, rope=None):
+    """Backward without re-layout passes or workspace (transpose-read kernels).  rope = (cos, sin) table: dq and dk leave
+    the kernels already rotated back (inverse RoPE fused into the epilogues: gradients w.r.t. the UN-rotated q, k)."""
     dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
     dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
     delta = torch.zeros(2, B, H, round_up(S, 64), dtype=torch.float32, device=q.device)  # [delta | lse*log2e]
     L.check(L.lib().mh_attn_bwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
                                  p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
-                                 p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)),
+                                 p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), p(rope),
                                  i32(dt_of(q)), _stream()), "mh_attn_bwd2")
     return dq, dk, dv
 

@@ -510,3 +510,43 @@ def test_decode_rope_append_and_attention(ops, dtype, B, H, D, Smax, lens):
         vh = vc[b, :L_].float().view(L_, H, D).permute(1, 0, 2)
         ref = torch.softmax(qh @ kh.transpose(1, 2) / D ** 0.5, dim=-1) @ vh
         assert relerr(o[b].float().view(H, 1, D), ref) < 3 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,D,K", [(2, 96, 2, 128, 256), (1, 613, 32, 128, 4096), (3, 50, 4, 64, 256), (2, 256, 1, 128, 128)])
+def test_gemm_with_fused_rope_is_bit_identical_to_gemm_then_rope(ops, dtype, B, S, H, D, K):
+    """The fused q|k|v projection + RoPE (staged GEMM epilogue) must reproduce mh_gemm_nt followed by mh_rope_qk bit for
+    bit: q and k heads rotated at position (row % S), v untouched; row counts that are not a multiple of the tile."""
+    T, d = B * S, H * D
+    x, w = rnd(T, K, dtype=dtype), rnd(3 * d, K, dtype=dtype, seed=1, scale=0.5)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    try:
+        ops.gemm_force_kernel(256)  # the fused form lives in the 256-tile kernel: same summation order for the reference
+        ref = ops.gemm_nt(x, w)
+    finally:
+        ops.gemm_force_kernel(0)
+    ops.rope_qk_(ref, tab, S, H, D)
+    got = ops.gemm_nt_rope(x, w, tab, S, H, D)
+    assert torch.equal(got, ref)
+    for _ in range(2):
+        assert torch.equal(ops.gemm_nt_rope(x, w, tab, S, H, D), got)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,D,causal", [(2, 200, 2, 128, True), (1, 577, 4, 64, False), (2, 256, 3, 128, True)])
+def test_attention_bwd_with_fused_inverse_rope(ops, dtype, B, S, H, D, causal):
+    """dq, dk rotated back inside the backward kernels' epilogues (fp32, before the single rounding) against the
+    separate path: attention backward, then the stand-alone inverse RoPE on the stored 16-bit gradients."""
+    d = H * D
+    qkv = rnd(B * S, 3 * d, dtype=dtype, scale=0.5)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o, lse = ops.attn_fwd2(q, k, v, B, S, H, D, causal)
+    do = rnd(B * S, d, dtype=dtype, seed=7, scale=0.5)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    dq, dk, dv = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal)
+    ref = torch.cat([dq, dk, dv], dim=1).contiguous()
+    ops.rope_qk_(ref, tab, S, H, D, inverse=True)
+    dq2, dk2, dv2 = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, rope=tab)
+    assert torch.equal(dv2, dv)
+    assert relerr(dq2, ref[:, :d].float()) < 2 * EPS16[dtype]
+    assert relerr(dk2, ref[:, d:2 * d].float()) < 2 * EPS16[dtype]

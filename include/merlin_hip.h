@@ -84,6 +84,14 @@ int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t l
  * D in {64, 128}; rope_cols % D == 0; N % 8 == 0; 16-byte aligned C rows. */
 int mh_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int dt,
                     const float* cos_sin, int S, int D, int rope_cols, void* stream);
+/* SwiGLU (HF LlamaMLP, modeling_llama.py:174-176) fused into the neighbouring GEMM's epilogue; both forms are bit-identical
+ * to the unfused sequence (GEMM, then mh_swiglu_fwd / mh_swiglu_bwd on the stored 16-bit tensor).
+ * fwd: gu[M, 2ff] = x Wgu^T (Wgu = [gate; up] rows) AND act[M, ff] = silu(gate) * up in one launch.
+ * bwd: dgu[M, 2ff] = swiglu'(gu) applied to dact = dy Wd, Wd = down_proj.weight [K = d_model, ff]; dact is never stored. */
+int mh_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* gu, int64_t ldgu, void* act, int64_t ldact,
+                       int M, int ff, int K, int dt, void* stream);
+int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, int64_t ldw, const void* gu, int64_t ldgu, void* dgu,
+                       int64_t lddgu, int M, int ff, int K, int dt, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,

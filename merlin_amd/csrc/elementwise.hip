@@ -10,7 +10,6 @@ inline int grid_for(int64_t nvec) {
   return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // out[t, f] = silu(gu[t, f]) * gu[t, ff + f]
 template <int DT>
@@ -24,7 +23,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_k(const uint16_t* __restrict__
     unpack8<DT>(*g, a);
     unpack8<DT>(*u, b);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = a[k] * sigmoidf_(a[k]) * b[k];
+    for (int k = 0; k < 8; ++k) a[k] = swiglu_fwd1(a[k], b[k]);
     ((uint4*)(out + t * ff))[c] = pack8<DT>(a);
   }
 }
@@ -41,9 +40,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const uint16_t* __restrict__
     unpack8<DT>(((const uint4*)(dout + t * ff))[c], d);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float s = sigmoidf_(a[k]);
-      du[k] = d[k] * a[k] * s;
-      dg[k] = d[k] * b[k] * s * (1.0f + a[k] * (1.0f - s));
+      swiglu_bwd1(a[k], b[k], d[k], dg[k], du[k]);
     }
     ((uint4*)(dgu + t * 2 * ff))[c] = pack8<DT>(dg);
     ((uint4*)(dgu + t * 2 * ff + ff))[c] = pack8<DT>(du);

@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
   }
 }
 
-struct RopeSpec { const float* tab = nullptr; int S = 0, D = 0, cols = 0; };
+struct RopeSpec {
+  const float* tab = nullptr; int S = 0, D = 0, cols = 0;
+  int sw_mode = 0, sw_ff = 0; void* sw_out = nullptr; const void* sw_in = nullptr; int64_t sw_ldo = 0, sw_ldi = 0;  // fused SwiGLU
+};
 static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                      int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
                      int epilogue, int splits, int64_t c_split, void* stream, RopeSpec rope = RopeSpec());
@@ -206,6 +209,24 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int a_kstrided, const void* B
                        int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
                        int epilogue, void* stream) {
   return gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, C, ldc, bias, resid, ldr, M, N, K, dt, epilogue, 1, 0, stream);
+}
+
+extern "C" int mh_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* gu, int64_t ldgu, void* act,
+                                  int64_t ldact, int M, int ff, int K, int dt, void* stream) {
+  if (!gu || !act || ff <= 0 || (ff & 7) || (ldgu & 7) || (ldact & 7) || ((((uintptr_t)gu) | ((uintptr_t)act)) & 15u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 1; r.sw_ff = ff; r.sw_out = act; r.sw_ldo = ldact;
+  return gemm_impl(x, ldx, 0, Wgu, ldw, 0, gu, ldgu, nullptr, nullptr, 0, M, 2 * ff, K, dt, 0, 1, 0, stream, r);
+}
+
+extern "C" int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, int64_t ldw, const void* gu, int64_t ldgu, void* dgu,
+                                  int64_t lddgu, int M, int ff, int K, int dt, void* stream) {
+  if (!gu || !dgu || ff <= 0 || (ff & 7) || (ldgu & 7) || (lddgu & 7) || ((((uintptr_t)gu) | ((uintptr_t)dgu)) & 15u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 2; r.sw_ff = ff; r.sw_out = dgu; r.sw_ldo = lddgu; r.sw_in = gu; r.sw_ldi = ldgu;
+  // dact[M, ff] = dy[M, K] * Wd[K, ff] (Wd is the down projection [d_model = K, ff] as stored: K-strided B); C stands in for
+  // the staging checks only (dact is never written)
+  return gemm_impl(dy, lddy, 0, Wd, ldw, 1, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt, 0, 1, 0, stream, r);
 }
 
 extern "C" int mh_gemm_splitk_max(int M, int N, int K) {
@@ -258,6 +279,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
+  g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;
   {
     static void* zp = nullptr;
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
@@ -278,17 +300,22 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
-  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab) {  // A/B arm: MFMA 32x32x16 fragments
+  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arm: MFMA 32x32x16 fragments
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
+  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
   }
-  if (big || a_kstrided || b_kstrided || splits > 1 || rope.tab) {  // K-strided operands / split-K / fused RoPE exist only in the 8-wave 256-tile kernel
+  if (rope.sw_mode == 1) {  // a tile = 128 gate + 128 up columns
+    g.tiles_m = (M + 255) / 256;
+    g.tiles_n = (rope.sw_ff + 127) / 128;
+    return launch_gemm_256(g, dt, 0, 0, as_stream(stream));
+  }
+  if (big || a_kstrided || b_kstrided || splits > 1 || rope.tab || rope.sw_mode) {  // K-strided operands / split-K / fused RoPE, SwiGLU exist only in the 8-wave 256-tile kernel
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_256(g, dt, a_kstrided, b_kstrided, as_stream(stream));

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
   tile_of_block(g, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * (g.sw_mode == 1 ? 128 : 256);
+  const int nB1 = g.sw_mode == 1 ? g.sw_ff + n0 : n0 + 128;  // first B row of the second half-tile
   // split-K: block y of grid.y takes K-tiles [kt0, kt0 + nk) and writes its own fp32 partial tile
   const int nk_total = (g.K + BK - 1) / BK;
   const int per_split = (nk_total + g.splits - 1) / g.splits;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
       const int row = qd >> 3, cc = qd & 7;
       const int c = (cc ^ ((row >> 1) & 7)) * 8;
       src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
-      src[H_B1][i] = g.B + (int64_t)min(n0 + 128 + row, g.N - 1) * g.ldb + c;
+      src[H_B1][i] = g.B + (int64_t)min(nB1 + row, g.N - 1) * g.ldb + c;
     } else {
       const int k = qd >> 4, cc = qd & 15;
       const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
@@ -297,6 +298,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     __syncthreads();
     const int ncol = n0 + (tid & 31) * 8;
     const bool n_ok = ncol < g.N;
+    if (g.sw_mode == 1) {
+      // fused SwiGLU forward: LDS columns 0-127 = gate [n0, n0+128), 128-255 = up ff + [n0, n0+128) (16-bit, rounded)
+      const int c = tid & 31;
+      const int col = n0 + (c & 15) * 8;  // gate / act column of this chunk
+      if (col < g.sw_ff) {
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+          const int row = pass * 16 + (tid >> 5);
+          if (m0 + row >= g.M) continue;
+          const uint4 mine = *(const uint4*)(smem + row * C_ROW + c * 16);
+          uint16_t* gu = (uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc;
+          if (c < 16) {
+            *(uint4*)(gu + col) = mine;
+            float ga[8], ub[8];
+            unpack8<DT>(mine, ga);
+            unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (c + 16) * 16), ub);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ga[k] = swiglu_fwd1(ga[k], ub[k]);
+            *(uint4*)((uint16_t*)g.sw_out + (int64_t)(m0 + row) * g.sw_ldo + col) = pack8<DT>(ga);
+          } else {
+            *(uint4*)(gu + g.sw_ff + col) = mine;
+          }
+        }
+      }
+      return;
+    }
+    if (g.sw_mode == 2) {
+      // fused SwiGLU backward: the staged tile is dact (rounded to 16 bits exactly as the unfused path stores it)
+      if (n_ok) {
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+          const int row = pass * 16 + (tid >> 5);
+          if (m0 + row >= g.M) continue;
+          float d_[8], ga[8], ub[8], dg[8], du[8];
+          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (tid & 31) * 16), d_);
+          const uint16_t* gu = (const uint16_t*)g.sw_in + (int64_t)(m0 + row) * g.sw_ldi;
+          unpack8<DT>(*(const uint4*)(gu + ncol), ga);
+          unpack8<DT>(*(const uint4*)(gu + g.sw_ff + ncol), ub);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+          uint16_t* dgu = (uint16_t*)g.sw_out + (int64_t)(m0 + row) * g.sw_ldo;
+          *(uint4*)(dgu + ncol) = pack8<DT>(dg);
+          *(uint4*)(dgu + g.sw_ff + ncol) = pack8<DT>(du);
+        }
+      }
+      return;
+    }
     if (g.rope_tab && ncol < g.rope_cols) {
       // fused RoPE (llama_flash_attn_monkey_patch.py:56-59): the tile holds whole heads (256 % D == 0), so the thread
       // that owns a low-half 8-channel chunk also reads its partner chunk D/2 channels later from the same LDS row and

@@ -19,6 +19,14 @@ struct GemmArgs {
   // at position (row % rope_S) with the (cos, sin) table rope_tab [pos][rope_D/2]; nullptr = off
   const float* rope_tab;
   int rope_S, rope_D, rope_cols;
+  // fused SwiGLU of the staged epilogue.  sw_mode 1 (forward, gate|up projection): a tile is 128 gate columns [n0, n0+128)
+  // + the 128 up columns ff + [n0, n0+128) (B rows taken from both halves of the fused weight); C = gu [M, 2 ff] is
+  // written as usual and sw_out = act [M, ff] = silu(gate) * up.  sw_mode 2 (backward, dact = dY Wd): the tile of dact is
+  // never stored; sw_out = dgu [M, 2 ff] from sw_in = gu [M, 2 ff].
+  int sw_mode, sw_ff;
+  void* sw_out;
+  const void* sw_in;
+  int64_t sw_ldo, sw_ldi;
 };
 
 constexpr int BK = 64;

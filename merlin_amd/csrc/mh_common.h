@@ -72,6 +72,16 @@ __device__ __forceinline__ void rope_rot(float a, float b, float c, float s, flo
   hi = fmaf(b, c, a * s);
 }
 
+// SwiGLU element maths, ONE definition (explicit fma) shared by the stand-alone kernels and the GEMM-epilogue forms so that
+// both round identically: act = silu(g) * u;  d_up = d * g * sig(g);  d_gate = d * u * sig(g) * (1 + g * (1 - sig(g)))
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swiglu_fwd1(float g, float u) { return g * sigmoidf_(g) * u; }
+__device__ __forceinline__ void swiglu_bwd1(float g, float u, float d, float& dg, float& du) {
+  const float s = sigmoidf_(g);
+  du = d * g * s;
+  dg = d * u * s * fmaf(g, 1.0f - s, 1.0f);
+}
+
 // ---- MFMA wrappers ------------------------------------------------------------------------
 // 16x16x32: A lane l holds A[i=l&15][k=8*(l>>4)..+8]; B lane l holds B[k=8*(l>>4)..+8][j=l&15];
 // D lane l reg r holds D[i=4*(l>>4)+r][j=l&15].

@@ -381,8 +381,7 @@ class HipEngine:
         o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         x2 = O.gemm_nt(o, W.wo, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-        gu = O.gemm_nt(h2, W.wgu)
-        act = O.swiglu_fwd(gu)
+        gu, act = O.gemm_swiglu_fwd(h2, W.wgu)  # gate|up projection; SwiGLU in the same launch's epilogue
         y = O.gemm_nt(act, W.wd, resid=x2)
         return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
 
@@ -399,12 +398,10 @@ class HipEngine:
         p = W.p
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
-        dact = O.gemm_nt(dy, W.wd, b_t=True)
+        dgu = O.gemm_swiglu_bwd(dy, W.wd, gu)  # dact = dy Wd never leaves the kernel: SwiGLU backward in the epilogue
         if train:
             self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
         del act
-        dgu = O.swiglu_bwd(gu, dact)
-        del dact
         dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
         if train:
             self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)

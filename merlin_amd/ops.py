@@ -199,6 +199,31 @@ def gemm_nt_rope(a, b, table, S, H, D, out=None):
     return out
 
 
+def gemm_swiglu_fwd(x, wgu):
+    """gu = x @ wgu^T ([gate; up] rows) and act = silu(gate) * up from ONE GEMM launch.  Returns (gu, act)."""
+    M, K = x.shape
+    ff = wgu.shape[0] // 2
+    gu = torch.empty(M, 2 * ff, dtype=x.dtype, device=x.device)
+    act = torch.empty(M, ff, dtype=x.dtype, device=x.device)
+    with _timed("gemm_nt", 2.0 * M * 2 * ff * K):
+        L.check(L.lib().mh_gemm_swiglu_fwd(p(x), i64(_rowmajor(x)), p(wgu), i64(_rowmajor(wgu)), p(gu), i64(2 * ff), p(act), i64(ff),
+                                           i32(M), i32(ff), i32(K), i32(dt_of(x)), _stream()), "mh_gemm_swiglu_fwd")
+    return gu, act
+
+
+def gemm_swiglu_bwd(dy, wd, gu):
+    """dgu = swiglu_bwd(gu, dy @ wd) with the SwiGLU backward in the dgrad GEMM's epilogue (dact never stored).
+    wd = down_proj.weight [d_model, ff]."""
+    M, K = dy.shape
+    ff = wd.shape[1]
+    assert wd.shape[0] == K and gu.shape == (M, 2 * ff)
+    dgu = torch.empty_like(gu)
+    with _timed("gemm_nt", 2.0 * M * ff * K):
+        L.check(L.lib().mh_gemm_swiglu_bwd(p(dy), i64(_rowmajor(dy)), p(wd), i64(_rowmajor(wd)), p(gu), i64(_rowmajor(gu)), p(dgu),
+                                           i64(_rowmajor(dgu)), i32(M), i32(ff), i32(K), i32(dt_of(dy)), _stream()), "mh_gemm_swiglu_bwd")
+    return dgu
+
+
 def transpose16(x, r_pad=None, out=None):
     """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
     R, Cc = x.shape

@@ -550,3 +550,26 @@ def test_attention_bwd_with_fused_inverse_rope(ops, dtype, B, S, H, D, causal):
     assert torch.equal(dv2, dv)
     assert relerr(dq2, ref[:, :d].float()) < 2 * EPS16[dtype]
     assert relerr(dk2, ref[:, d:2 * d].float()) < 2 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,ff,K", [(300, 256, 128), (1000, 1408, 256), (613, 11008, 4096), (4096, 512, 256)])
+def test_gemm_with_fused_swiglu_is_bit_identical_to_unfused(ops, dtype, M, ff, K):
+    """SwiGLU in the GEMM epilogues (forward: gate|up projection also emits act; backward: the down-projection dgrad emits
+    dgu without storing dact) against GEMM + stand-alone SwiGLU kernels on the stored 16-bit tensors: bit for bit."""
+    x, wgu = rnd(M, K, dtype=dtype), rnd(2 * ff, K, dtype=dtype, seed=1, scale=0.5)
+    try:
+        ops.gemm_force_kernel(256)
+        gu_ref = ops.gemm_nt(x, wgu)
+    finally:
+        ops.gemm_force_kernel(0)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    gu, act = ops.gemm_swiglu_fwd(x, wgu)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    # backward: dy [M, d], wd [d, ff]
+    d = K
+    dy, wd = rnd(M, d, dtype=dtype, seed=2, scale=0.5), rnd(d, ff, dtype=dtype, seed=3, scale=0.5)
+    dact = ops.gemm_nt(dy, wd, b_t=True)
+    dgu_ref = ops.swiglu_bwd(gu_ref, dact)
+    dgu = ops.gemm_swiglu_bwd(dy, wd, gu_ref)
+    assert torch.equal(dgu, dgu_ref)

@@ -244,6 +244,9 @@ int mh_adamw_clip(void* p, const void* g, float* m, float* v, int64_t n, float l
 int mh_clip_scale(const float* sumsq, float gscale, float max_norm, float* out2, void* stream);
 /* out[0] += sum(g^2) over n elements (fp32 atomic; zero it first) */
 int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream);
+/* Deterministic form (fixed grid, fixed-order two-stage sum; 16-byte loads): out[0] = sum g^2; `partial` = 2048 floats
+ * of scratch.  Used for gradient clipping so that the clip coefficient - and therefore training - is run-to-run reproducible. */
+int mh_sumsq_det(const void* g, int64_t n, float* partial, float* out, int dt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -221,6 +221,37 @@ __global__ __launch_bounds__(256) void sumsq_k(const uint16_t* __restrict__ g, i
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// deterministic form: 16-byte loads, one partial per block (fixed grid), then a fixed-order final sum
+template <int DT>
+__global__ __launch_bounds__(256) void sumsq_part_k(const uint16_t* __restrict__ g, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float x[8];
+    unpack8<DT>(((const uint4*)g)[i], x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaf(x[k], x[k], s);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const float x = ld16<DT>(g[(nvec << 3) + threadIdx.x]);
+    s = fmaf(x, x, s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_k(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
 
 #define DISPATCH16(dt, KERNEL, GRID, ...)                                                                       \
@@ -324,5 +355,12 @@ extern "C" int mh_clip_scale(const float* sumsq, float gscale, float max_norm, f
 extern "C" int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream) {
   if (!g || !out || n <= 0) return MH_ERR_ARG;
   DISPATCH16(dt, sumsq_k, grid_for(n), (const uint16_t*)g, n, out);
+  MH_LAUNCH_CHECK();
+}
+extern "C" int mh_sumsq_det(const void* g, int64_t n, float* partial, float* out, int dt, void* stream) {
+  if (!g || !partial || !out || n <= 0 || ((uintptr_t)g & 15u)) return MH_ERR_ARG;
+  const int grid = grid_for(n >> 3);
+  DISPATCH16(dt, sumsq_part_k, grid, (const uint16_t*)g, n, partial);
+  hipLaunchKernelGGL(sumsq_final_k, dim3(1), dim3(256), 0, as_stream(stream), (const float*)partial, grid, out);
   MH_LAUNCH_CHECK();
 }

@@ -502,6 +502,10 @@ def clip_scale(sumsq_t, gscale, max_norm, out2):
     L.check(L.lib().mh_clip_scale(p(sumsq_t), f32(gscale), f32(max_norm), p(out2), _stream()), "mh_clip_scale")
 
 
+def sumsq_det(g, partial, out):
+    L.check(L.lib().mh_sumsq_det(p(g), i64(g.numel()), p(partial), p(out), i32(dt_of(g)), _stream()), "mh_sumsq_det")
+
+
 def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
 

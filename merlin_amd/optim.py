@@ -83,6 +83,7 @@ class FusedAdamW:
         self._runs = None
         self._flat_id = None
         self._clip = None
+        self._ss = None
 
     def _build(self):
         A = self.engine.ensure_arena()
@@ -144,9 +145,10 @@ class FusedAdamW:
     def grad_norm_sq(self):
         """Sum of squares of the gradient arena (device scalar tensor; frozen parameters hold zeros)."""
         A = self.engine.arena
-        out = torch.zeros(1, dtype=torch.float32, device=A.flat.device)
-        O.sumsq(A.gflat, out)
-        return out
+        if self._ss is None or self._ss.device != A.flat.device:
+            self._ss = torch.zeros(2049, dtype=torch.float32, device=A.flat.device)
+        O.sumsq_det(A.gflat, self._ss[1:], self._ss[:1])  # fixed-order reduction: reproducible clip coefficient
+        return self._ss[:1]
 
     def grad_norm(self):
         """Global L2 norm of the gradient arena (device scalar tensor)."""

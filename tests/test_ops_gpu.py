@@ -573,3 +573,17 @@ def test_gemm_with_fused_swiglu_is_bit_identical_to_unfused(ops, dtype, M, ff, K
     dgu_ref = ops.swiglu_bwd(gu_ref, dact)
     dgu = ops.gemm_swiglu_bwd(dy, wd, gu_ref)
     assert torch.equal(dgu, dgu_ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [8, 4099, 1 << 20, (1 << 22) + 5])
+def test_sumsq_deterministic(ops, dtype, n):
+    g = rnd(n + 8, dtype=dtype, scale=0.3)[:n]  # (any length; 16-byte aligned base)
+    part, out = torch.zeros(2048, device=dev()), torch.zeros(1, device=dev())
+    ops.sumsq_det(g, part, out)
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(out) - ref) / ref < 1e-5
+    first = out.clone()
+    for _ in range(3):
+        ops.sumsq_det(g, part, out)
+        assert torch.equal(out, first)

@@ -41,25 +41,26 @@ __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// D/8 lanes per (token, head) row: one 16-byte load of O and of dO per lane, shuffle reduction within the lane group
 template <int DT, int D>
 __global__ __launch_bounds__(256) void delta2_k(Bwd2Args a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 4 + wave;  // over B*S*H
-  if (idx >= (int64_t)a.B * a.S * a.H) return;
-  const int h = (int)(idx % a.H);
-  const int64_t t = idx / a.H;
+  constexpr int LPR = D / 8, RPB = 256 / LPR;  // lanes per row, rows per block
+  const int part = threadIdx.x % LPR;
+  const int64_t idx = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;  // over B*S*H
+  const bool ok = idx < (int64_t)a.B * a.S * a.H;
+  const int64_t ic = ok ? idx : 0;
+  const int h = (int)(ic % a.H);
+  const int64_t t = ic / a.H;
   const int b = (int)(t / a.S), s = (int)(t % a.S);
-  float acc;
-  if constexpr (D == 128) {
-    float x0, x1, y0, y1;
-    unpack2<DT>(*(const uint32_t*)(a.o + t * a.ldo + (int64_t)h * D + lane * 2), x0, x1);
-    unpack2<DT>(*(const uint32_t*)(a.dout + t * a.lddo + (int64_t)h * D + lane * 2), y0, y1);
-    acc = x0 * y0 + x1 * y1;
-  } else {
-    acc = ld16<DT>(a.o[t * a.ldo + (int64_t)h * D + lane]) * ld16<DT>(a.dout[t * a.lddo + (int64_t)h * D + lane]);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) {
+  float x[8], y[8];
+  unpack8<DT>(*(const uint4*)(a.o + t * a.ldo + (int64_t)h * D + part * 8), x);
+  unpack8<DT>(*(const uint4*)(a.dout + t * a.lddo + (int64_t)h * D + part * 8), y);
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc = fmaf(x[e], y[e], acc);
+#pragma unroll
+  for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
+  if (ok && part == 0) {
     const int64_t i = ((int64_t)b * a.H + h) * a.S_pad + s;
     a.delta[i] = -acc;
     ((float*)a.lse2)[i] = -a.lse[i] * a.inv_scale;
@@ -447,7 +448,8 @@ int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
     attr = true;
   }
   const int64_t nth = (int64_t)a.B * a.S * a.H;
-  hipLaunchKernelGGL((delta2_k<DT, D>), dim3((unsigned)((nth + 3) / 4)), dim3(256), 0, st, a);
+  constexpr int RPB = 256 / (D / 8);
+  hipLaunchKernelGGL((delta2_k<DT, D>), dim3((unsigned)((nth + RPB - 1) / RPB)), dim3(256), 0, st, a);
   dim3 grid(xcd_grid(a.B * a.H, (a.S + 127) / 128));
   hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 1>), grid, dim3(256), ldsKV, st, a);
   hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 2>), grid, dim3(256), ldsKV, st, a);
@@ -464,7 +466,7 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
                             int causal, const float* rope_cos_sin, int dt, void* stream) {
   using namespace mhattn;
   if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return MH_ERR_ARG;
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 1) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
   if (D != 128 && D != 64) return MH_ERR_SHAPE;
   Bwd2Args a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o;

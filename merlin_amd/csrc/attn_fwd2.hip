@@ -156,10 +156,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // Lazy rescaling: the running reference m_run only moves when the row maximum grows by more than 2^8 (P stays <= 256,
+    // exact in fp32 accumulation and well inside the 16-bit range); the result is the same softmax - any reference works
+    // as long as O and l use the same one - but after the first few tiles no lane needs a rescale and the 16*DBLK
+    // multiplies of the O accumulators are skipped for the whole wave.
     const float m_new = fmaxf(m_run, mx * sc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // rows with every key masked so far
-    const float alpha = fast_exp2(m_run - m_use);
-    m_run = m_new;
+    const bool need = m_new > m_run + 8.0f;
+    float alpha = 1.0f;
+    if (need) {
+      alpha = fast_exp2(m_run - m_new);  // (first tile: exp2(-inf) = 0)
+      m_run = m_new;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;  // rows with every key masked so far
     float psum = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
@@ -170,10 +178,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
         psum += p;
       }
     l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < DBLK; ++i)
+      for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
     // P fragments: k-step s uses regs 8*(s&1)..+7 of key block s>>1
     u32x4_t pf[4];
 #pragma unroll

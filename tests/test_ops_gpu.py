@@ -587,3 +587,32 @@ def test_sumsq_deterministic(ops, dtype, n):
     for _ in range(3):
         ops.sumsq_det(g, part, out)
         assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_fwd_lazy_rescale_with_growing_row_maxima(ops, dtype, causal):
+    """Scores whose row maximum keeps growing along the key axis by far more than the lazy-rescale threshold (2^8), and
+    rows whose maximum sits in the first tile: the running reference must move exactly when needed."""
+    B, S, H, D = 1, 512, 2, 128
+    d = H * D
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q = torch.randn(B * S, d, generator=g)
+    k = torch.randn(B * S, d, generator=g)
+    ramp = torch.linspace(0.2, 6.0, S)[:, None]           # later keys have much larger norms -> growing maxima
+    k = k * ramp
+    k[5] *= 8.0                                           # an early dominant key (maximum in the first tile for rows >= 5)
+    v = torch.randn(B * S, d, generator=g)
+    qkv = torch.cat([q, k, v], dim=1).to(dtype).to(dev()).contiguous()
+    q_, k_, v_ = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o, lse = ops.attn_fwd2(q_, k_, v_, B, S, H, D, causal)
+    qh = q_.float().view(S, H, D).permute(1, 0, 2)
+    kh = k_.float().view(S, H, D).permute(1, 0, 2)
+    vh = v_.float().view(S, H, D).permute(1, 0, 2)
+    sc = qh @ kh.transpose(1, 2) / D ** 0.5
+    if causal:
+        sc = sc.masked_fill(torch.ones(S, S, device=dev()).triu(1).bool(), float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ vh).permute(1, 0, 2).reshape(S, d)
+    assert relerr(o, ref) < 4 * EPS16[dtype]
+    lse_ref = torch.logsumexp(sc, dim=-1)                 # [H, S]
+    assert float((lse[0, :, :S] - lse_ref).abs().max()) < 2e-2 * max(1.0, float(lse_ref.abs().max()) * 0.05)

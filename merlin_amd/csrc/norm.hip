@@ -10,6 +10,7 @@
 
 namespace {
 
+#define TOUCH4(q_) asm volatile("" : "+v"((q_).x), "+v"((q_).y), "+v"((q_).z), "+v"((q_).w))
 constexpr int ROWS_PER_BLOCK = 4;
 constexpr int MAX_PARTIALS = 1024;
 
@@ -105,19 +106,39 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(rows, r_begin + rows_per_block);
   const float invd = 1.0f / (float)d;
+  // the weight row is loop-invariant: keep it packed in registers
+  uint4 wraw[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    wraw[j] = c < nch ? wr[c] : make_uint4(0, 0, 0, 0);
+  }
   for (int row = r_begin + wave; row < r_end; row += ROWS_PER_BLOCK) {
     const uint4* xr = (const uint4*)(x + (int64_t)row * d);
     const uint4* gr = (const uint4*)(dy + (int64_t)row * d);
     uint4* dxr = (uint4*)(dx + (int64_t)row * d);
-    float xs[NCH][8], gs[NCH][8];  // x (then xhat) and g = w * dy
+    // every load of the row (x, dy and, when accumulating, the old dx) is issued before anything is consumed; the
+    // values stay PACKED in registers (3 x NCH uint4) and are unpacked on the fly in each pass - three times the
+    // bytes in flight per wave of the unpack-first form, which ran at 3.7 TB/s
+    uint4 xraw[NCH], graw[NCH], praw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        xraw[j] = xr[c];
+        graw[j] = gr[c];
+        if (accumulate_dx) praw[j] = dxr[c];
+      }
+    }
     float s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
-        unpack8<DT>(xr[c], xs[j]);
+        float xs[8];
+        unpack8<DT>(xraw[j], xs);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s1 += LN ? xs[j][i] : xs[j][i] * xs[j][i];
+        for (int i = 0; i < 8; ++i) s1 += LN ? xs[i] : xs[i] * xs[i];
       }
     }
     float mu = 0.f, r;
@@ -128,46 +149,60 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x
       for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
         if (c < nch) {
+          float xs[8];
+          unpack8<DT>(xraw[j], xs);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ss += (xs[j][i] - mu) * (xs[j][i] - mu);
+          for (int i = 0; i < 8; ++i) ss += (xs[i] - mu) * (xs[i] - mu);
         }
       }
       r = rsqrtf(wave_sum(ss) * invd + eps);
     } else {
       r = rsqrtf(wave_sum(s1) * invd + eps);
     }
+    // (opaque touches: without them hipcc keeps the UNPACKED fp32 copies alive across the passes - 405 VGPRs, one wave
+    // per SIMD - instead of re-unpacking the packed registers)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { TOUCH4(xraw[j]); TOUCH4(graw[j]); }
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
-        float dyf[8], wf[8];
-        unpack8<DT>(gr[c], dyf);
-        unpack8<DT>(wr[c], wf);
+        float xs[8], dyf[8], wf[8];
+        unpack8<DT>(xraw[j], xs);
+        unpack8<DT>(graw[j], dyf);
+        unpack8<DT>(wraw[j], wf);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float xh = (xs[j][i] - mu) * r;  // xhat (RMS: mu = 0)
-          xs[j][i] = xh;
-          gs[j][i] = wf[i] * dyf[i];
+          const float xh = (xs[i] - mu) * r;  // xhat (RMS: mu = 0)
+          const float gsv = wf[i] * dyf[i];
           dwacc[j][i] += dyf[i] * xh;
           if (LN) dbacc[j][i] += dyf[i];
-          sg += gs[j][i];
-          sgx += gs[j][i] * xh;
+          sg += gsv;
+          sgx += gsv * xh;
         }
       }
     }
     sgx = wave_sum(sgx) * invd;
     if (LN) sg = wave_sum(sg) * invd; else sg = 0.f;
 #pragma unroll
+    for (int j = 0; j < NCH; ++j) { TOUCH4(xraw[j]); TOUCH4(graw[j]); TOUCH4(wraw[j]); }
+#pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
-        float o[8];
+        float xs[8], dyf[8], wf[8], o[8];
+        unpack8<DT>(xraw[j], xs);
+        unpack8<DT>(graw[j], dyf);
+        unpack8<DT>(wraw[j], wf);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = r * (gs[j][i] - sg - xs[j][i] * sgx);
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (xs[i] - mu) * r;
+          o[i] = r * (wf[i] * dyf[i] - sg - xh * sgx);
+        }
         if (accumulate_dx) {
           float p[8];
-          unpack8<DT>(dxr[c], p);
+          unpack8<DT>(praw[j], p);
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += p[i];
         }

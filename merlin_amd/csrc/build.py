@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_m32.hip", "gemm256w4.hip", "norm.hip", "elementwise.hip", "attn_fwd.hip", "attn_fwd2.hip", "attn_bwd.hip", "attn_bwd_kv.hip", "attn_bwd2.hip", "loss_splice.hip", "conv.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_m32.hip", "gemm256w4.hip", "gemm256w8.hip", "norm.hip", "elementwise.hip", "attn_fwd.hip", "attn_fwd2.hip", "attn_bwd.hip", "attn_bwd_kv.hip", "attn_bwd2.hip", "loss_splice.hip", "conv.hip", "decode.hip"]
 LIB = os.path.join(HERE, "libmerlin_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 

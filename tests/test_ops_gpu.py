@@ -427,7 +427,7 @@ def test_wgrad_tn_any_tokens_splitk(ops, dtype, T, No, Ki):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1000, 515, 256), (613, 4096, 1024),
                                    (2048, 2048, 4096), (300, 103, 64), (4096, 11008, 512)])
-@pytest.mark.parametrize("which", [256, 4])
+@pytest.mark.parametrize("which", [256, 4, 88])
 def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
     """The pipelined 256x256 kernels (forced: 256 = 8 waves, 4 = 4 waves x 128x128 with AGPR accumulators), incl.
     M/N edges, short K (prologue/tail clamps) and epilogues (direct and LDS-staged); repeated to catch pipeline

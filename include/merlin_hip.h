@@ -175,6 +175,12 @@ int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
  * or fp32.  K % 8 == 0, 16-byte aligned rows. */
 int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid, int64_t ldr,
             int M, int N, int K, int dt, int out_f32, void* stream);
+/* fp8 weight path of the decode step (BASELINE cfg 5's weight format: OCP e4m3 values, one fp32 scale per 128
+ * consecutive k of a row; activations stay `dt`).  mh_quant_fp8_b128: q[N, K] bytes + scales[N, ceil(K/128)] from
+ * w[N, K] (`dt`).  mh_gemv_fp8w: as mh_gemv with the weight given as (q, scales); K % 16 == 0. */
+int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* scales, int N, int K, int dt, void* stream);
+int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
+                 int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream);
 /* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */
 int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,

@@ -108,6 +108,90 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   }
 }
 
+// ---- fp8 (OCP e4m3) weights with one fp32 scale per 128 consecutive k (BASELINE cfg 5's weight format), bf16/f16
+// activations: the decode step is weight-bandwidth-bound, so halving the weight bytes is worth ~2x on the GEMVs.
+// quant: q[n, k] = fp8(w[n, k] / s[n, k/128]),  s = max|w| over the block / 448 (1 if the block is all zero).
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_b128_k(const uint16_t* __restrict__ w, int64_t ldw, uint8_t* __restrict__ q,
+                                                        float* __restrict__ sc, int N, int K) {
+  const int nb = (K + 127) / 128;
+  const int64_t blk = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // 16 lanes per 128-element block
+  if (blk >= (int64_t)N * nb) return;
+  const int n = (int)(blk / nb), kb = (int)(blk % nb);
+  const int k0 = kb * 128 + (threadIdx.x & 15) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (k0 < K) unpack8<DT>(*(const uint4*)(w + (int64_t)n * ldw + k0), v);
+  float mx = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+#pragma unroll
+  for (int o2 = 8; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+  const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if ((threadIdx.x & 15) == 0) sc[(int64_t)n * nb + kb] = s;
+  if (k0 < K) {
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, p1, true);
+    *(uint2*)(q + (int64_t)n * K + k0) = make_uint2((unsigned)p0, (unsigned)p1);
+  }
+}
+
+__device__ __forceinline__ void fp8x4_to_f32(uint32_t p, float* f) {
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+  const f2_ lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, true);
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+
+// y[m, n] = sum_kb s[n, kb] * sum_{k in block} q[n, k] x[m, k] (+ resid): one wave per weight row, 16 fp8 (16 B) per lane
+// and step (a lane's 16 values lie inside one 128-block), fp32 accumulate.  K % 16 == 0.
+template <int DT, int MM>
+__global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ q,
+                                                   const float* __restrict__ sc, void* __restrict__ out, int64_t ldo,
+                                                   const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int nb = (K + 127) / 128;
+  float acc[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+  const uint8_t* qrow = q + (int64_t)n * K;
+  const float* srow = sc + (int64_t)n * nb;
+  for (int k0 = lane * 16; k0 < K; k0 += 1024) {
+    const uint4 qv = *(const uint4*)(qrow + k0);
+    const float s = srow[k0 >> 7];
+    float w[16];
+    fp8x4_to_f32(qv.x, w); fp8x4_to_f32(qv.y, w + 4); fp8x4_to_f32(qv.z, w + 8); fp8x4_to_f32(qv.w, w + 12);
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      float xa[8], xb[8];
+      unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + k0), xa);
+      unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + k0 + 8), xb);
+      float p = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p = fmaf(w[e], xa[e], p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p = fmaf(w[8 + e], xb[e], p);
+      acc[m] = fmaf(s, p, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = wave_sum(acc[m]);
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      float v = acc[m];
+      if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+      if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+      else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+    }
+  }
+}
+
 // qkv [B, 3, H, D] of the new tokens; tab [max_pos, D/2] (cos, sin); kc, vc [B, Smax, H*D]
 template <int DT>
 __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv, const float2* __restrict__ tab,
@@ -344,6 +428,39 @@ extern "C" int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, co
   } while (0)
   if (dt == MH_BF16) { if (D == 128) GO(MH_BF16, 128); else GO(MH_BF16, 64); }
   else { if (D == 128) GO(MH_F16, 128); else GO(MH_F16, 64); }
+#undef GO
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* scales, int N, int K, int dt, void* stream) {
+  if (!w || !q || !scales || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || !aligned16(w)) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int64_t blocks = (int64_t)N * ((K + 127) / 128);
+  const dim3 grid((unsigned)((blocks + 15) / 16)), block(256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(quant_fp8_b128_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)w, ldw, (uint8_t*)q, scales, N, K);
+  else
+    hipLaunchKernelGGL(quant_fp8_b128_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)w, ldw, (uint8_t*)q, scales, N, K);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
+                            int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+  if (!x || !q || !scales || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
+  if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const dim3 grid((N + 3) / 4), block(256);
+  hipStream_t st = as_stream(stream);
+#define GO(DT_, MM_)                                                                                                         \
+  hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_>), grid, block, 0, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, \
+                     (const uint16_t*)resid, ldr, N, K, out_f32)
+#define GOM(DT_)                                                                                                   \
+  switch (M) {                                                                                                     \
+    case 1: GO(DT_, 1); break; case 2: GO(DT_, 2); break; case 3: GO(DT_, 3); break; case 4: GO(DT_, 4); break;   \
+    case 5: GO(DT_, 5); break; case 6: GO(DT_, 6); break; case 7: GO(DT_, 7); break; default: GO(DT_, 8); break;   \
+  }
+  if (dt == MH_BF16) { GOM(MH_BF16); } else { GOM(MH_F16); }
+#undef GOM
 #undef GO
   MH_LAUNCH_CHECK();
 }

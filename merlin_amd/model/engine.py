@@ -640,9 +640,27 @@ class HipEngine:
         cache.lens.copy_(lens if lens is not None else torch.full((B,), S, dtype=torch.int32, device=A.flat.device))
         return logits, cache
 
-    def decode_step(self, tokens, cache):
+    def quantize_decode_weights(self):
+        """fp8 (OCP e4m3, one scale per 128 k) copies of the decoder's Linear weights for the decode step (BASELINE cfg 5's
+        weight format; activations stay 16-bit).  ~half the bytes per token.  Re-run after the weights change."""
+        self.ensure_arena()
+        A = self.arena
+        cfg = self.model.config
+        V, d = cfg.vocab_size, cfg.hidden_size
+        q = []
+        for W in self.llama:
+            q.append(dict(wqkv=O.quant_fp8_b128(W.wqkv), wo=O.quant_fp8_b128(W.wo), wgu=O.quant_fp8_b128(W.wgu), wd=O.quant_fp8_b128(W.wd)))
+        Vpad = _ru(V, 64)
+        wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
+        self._fp8 = dict(layers=q, lm_head=O.quant_fp8_b128(wlm[:V]))
+        return self._fp8
+
+    def decode_step(self, tokens, cache, fp8=False):
         """One new token per sequence (tokens int64 [B]) at position cache.lens[b]; returns logits fp32 [B, V] and
-        advances the cache.  Every op is an HBM-bound kernel: weights and cache are streamed exactly once."""
+        advances the cache.  Every op is an HBM-bound kernel: weights and cache are streamed exactly once.
+        fp8=True uses the fp8 weight copies of quantize_decode_weights()."""
+        if fp8:
+            return self._decode_step_fp8(tokens, cache)
         cfg = self.model.config
         A = self.arena
         d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
@@ -667,7 +685,32 @@ class HipEngine:
         cache.lens.add_(1)  # in place (after every kernel that read it as `pos`): the captured graph sees the same buffer
         return logits
 
-    def capture_decode_graph(self, cache):
+    def _decode_step_fp8(self, tokens, cache):
+        cfg = self.model.config
+        A = self.arena
+        F8 = getattr(self, "_fp8", None) or self.quantize_decode_weights()
+        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
+        eps = cfg.rms_norm_eps
+        emb = A.view("model.embed_tokens.weight", shape=(V, d))
+        x = emb.index_select(0, tokens.to(A.flat.device).view(-1))
+        pos = cache.lens
+        lens1 = pos + 1
+        for li, W in enumerate(self.llama):
+            Q = F8["layers"][li]
+            h1 = O.rmsnorm_fwd(x, W.ln1, eps)
+            qkv = O.gemv_fp8w(h1, Q["wqkv"])
+            O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
+            o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
+            x2 = O.gemv_fp8w(o, Q["wo"], resid=x)
+            h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+            act = O.swiglu_fwd(O.gemv_fp8w(h2, Q["wgu"]))
+            x = O.gemv_fp8w(act, Q["wd"], resid=x2)
+        hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
+        logits = O.gemv_fp8w(hn, F8["lm_head"], out_f32=True)
+        cache.lens.add_(1)
+        return logits
+
+    def capture_decode_graph(self, cache, fp8=False):
         """Capture one decode step (≈300 launches) into a HIP graph bound to `cache`: returns (graph, token buffer int64 [B],
         logits buffer fp32 [B, V]).  Positions live in cache.lens on the device and advance inside the graph, so every
         replay is the next token.  One eager warm-up step runs first (function attributes, symbol look-ups and allocator
@@ -678,12 +721,12 @@ class HipEngine:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            self.decode_step(tok, cache)
+            self.decode_step(tok, cache, fp8=fp8)
         torch.cuda.current_stream(dev).wait_stream(side)
         cache.lens.copy_(keep)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            logits = self.decode_step(tok, cache)
+            logits = self.decode_step(tok, cache, fp8=fp8)
         cache.lens.copy_(keep)  # capture does not execute, but keep the invariant explicit
         return g, tok, logits
 

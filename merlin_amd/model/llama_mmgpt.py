@@ -222,11 +222,12 @@ class MMGPTLlamaForCausalLM(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens=32, eos_token_id=None, do_sample=False,
-                 use_cache=True, num_beams=1, use_graph=True, **kw):
+                 use_cache=True, num_beams=1, use_graph=True, fp8_weights=False, **kw):
         """Greedy decoding (eval_mmvet.py:101-120 calls `model.generate(input_ids, images=[...], ...)`).
         use_cache=True: one prefill over the prompt fills a KV cache, then one HBM-bound decode step per token
         (llama_mmgpt.py:114-134 semantics: only the last token is fed, images are consumed by the prefill only);
-        use_graph replays the step as one captured HIP graph instead of ~300 separate launches.
+        use_graph replays the step as one captured HIP graph instead of ~300 separate launches; fp8_weights decodes with
+        fp8 (e4m3, per-128-block scales) copies of the decoder weights - half the bytes per token, the prefill stays 16-bit.
         use_cache=False: full-sequence recompute per token (kept as the cross-check).  Prompts may be right-padded
         (attention_mask); finished sequences keep emitting eos.  Sampling and beam search are not implemented."""
         if do_sample or num_beams != 1:
@@ -247,7 +248,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
         B = input_ids.shape[0]
         graph = None
         if use_graph and logits.is_cuda and max_new_tokens > 2:
-            graph, g_tok, g_logits = self.engine.capture_decode_graph(cache)  # the decode step as one replayable HIP graph
+            graph, g_tok, g_logits = self.engine.capture_decode_graph(cache, fp8=fp8_weights)  # the decode step as one replayable HIP graph
         done = torch.zeros(B, dtype=torch.bool, device=logits.device)
         new = []
         for step in range(max_new_tokens):
@@ -263,7 +264,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
                 graph.replay()
                 logits = g_logits
             else:
-                logits = self.engine.decode_step(nxt, cache)
+                logits = self.engine.decode_step(nxt, cache, fp8=fp8_weights)
         new = torch.stack(new, dim=1).to(input_ids.device)
         if attention_mask is None:
             return torch.cat([input_ids, new], dim=1)

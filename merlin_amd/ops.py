@@ -141,6 +141,33 @@ def gemv(x, w, out=None, resid=None, out_f32=False, n=None):
     return out
 
 
+def quant_fp8_b128(w):
+    """w [N, K] (16-bit) -> (q uint8 [N, K] OCP e4m3, scales fp32 [N, ceil(K/128)])."""
+    N, K = w.shape
+    q = torch.empty(N, K, dtype=torch.uint8, device=w.device)
+    sc = torch.empty(N, (K + 127) // 128, dtype=torch.float32, device=w.device)
+    L.check(L.lib().mh_quant_fp8_b128(p(w), i64(_rowmajor(w)), p(q), p(sc), i32(N), i32(K), i32(dt_of(w)), _stream()), "mh_quant_fp8_b128")
+    return q, sc
+
+
+def gemv_fp8w(x, qw, out=None, resid=None, out_f32=False, n=None):
+    """out[M, N] = x[M, K] @ dequant(q, scales)^T (+ resid); qw = (q, scales) from quant_fp8_b128."""
+    q, sc = qw
+    M, K = x.shape
+    N = q.shape[0] if n is None else n
+    assert q.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    for m0 in range(0, M, 8):
+        mm = min(8, M - m0)
+        xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
+        rs = resid[m0:m0 + mm] if resid is not None else None
+        L.check(L.lib().mh_gemv_fp8w(p(xs), i64(_rowmajor(xs)), p(q), p(sc), p(os_), i64(_rowmajor(os_)), p(rs),
+                                     i64(_rowmajor(rs) if rs is not None else 0), i32(mm), i32(N), i32(K), i32(dt_of(x)),
+                                     i32(int(out.dtype == torch.float32)), _stream()), "mh_gemv_fp8w")
+    return out
+
+
 def decode_rope_append(qkv, table, pos, kcache, vcache, H, D):
     """qkv [B, 3*H*D] of the new tokens (rotated in place at pos[b]); k, v appended to kcache/vcache [B, Smax, H*D]."""
     B = qkv.shape[0]

@@ -404,3 +404,26 @@ def test_ragged_batch_equals_per_sequence_runs_at_real_widths(dtype):
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, g_pad[k]), k
+
+
+def test_fp8_weight_decode_tracks_16bit_decode():
+    """Decode with fp8 (e4m3, per-128-block scales) decoder weights against the 16-bit decode on the same cache: the
+    logits that pick each token differ only by the weight quantisation (stated tolerance: 6e-2 of the logit range on the
+    2-layer model; the prefill and the cache are identical)."""
+    from oracle import cases as C
+
+    cfg, batch = C.get_case("tiny_1img")
+    model = _build(cfg, torch.bfloat16)
+    b = _to_dev(batch)
+    n_new = 5
+    logits, cache = model.engine.prefill(b["input_ids"], b["attention_mask"], b["images"], n_new)
+    logits8, cache8 = model.engine.prefill(b["input_ids"], b["attention_mask"], b["images"], n_new)
+    assert torch.equal(logits, logits8)
+    for _ in range(n_new - 1):
+        nxt = logits.argmax(dim=-1)
+        logits = model.engine.decode_step(nxt, cache)
+        logits8 = model.engine.decode_step(nxt, cache8, fp8=True)   # teacher-forced on the 16-bit path's tokens
+        err = float((logits8 - logits).abs().max() / logits.abs().max())
+        assert err < 6e-2, err
+    out = model.generate(b["input_ids"], images=b["images"], max_new_tokens=4, fp8_weights=True, eos_token_id=-1)
+    assert out.shape == (1, b["input_ids"].shape[1] + 4)

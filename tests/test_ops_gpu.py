@@ -616,3 +616,33 @@ def test_attention_fwd_lazy_rescale_with_growing_row_maxima(ops, dtype, causal):
     assert relerr(o, ref) < 4 * EPS16[dtype]
     lse_ref = torch.logsumexp(sc, dim=-1)                 # [H, S]
     assert float((lse[0, :, :S] - lse_ref).abs().max()) < 2e-2 * max(1.0, float(lse_ref.abs().max()) * 0.05)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1000, 1024), (3, 515, 272), (2, 256, 11008)])
+def test_fp8_block_quant_and_gemv(ops, dtype, M, N, K):
+    """fp8 weight path of the decode step: the quantiser must produce OCP e4m3 bytes (checked by reinterpreting them as
+    torch.float8_e4m3fn) with scale = max|block| / 448, and the GEMV must equal x @ dequant(q, s)^T to fp32 accuracy; the
+    quantisation error itself is bounded by the format (3 mantissa bits: <= 2^-4 relative per element)."""
+    w = rnd(N, K, dtype=dtype, scale=0.05)
+    w[0, :128] = 0                                        # an all-zero block
+    x = rnd(M, K, dtype=dtype, seed=1)
+    q, s = ops.quant_fp8_b128(w)
+    nb = (K + 127) // 128
+    assert q.shape == (N, K) and s.shape == (N, nb)
+    wpad = torch.nn.functional.pad(w.float(), (0, nb * 128 - K)).view(N, nb, 128)
+    s_ref = wpad.abs().amax(dim=2) / 448.0
+    s_ref = torch.where(s_ref > 0, s_ref, torch.ones_like(s_ref))
+    assert torch.allclose(s, s_ref, rtol=1e-6, atol=0)
+    deq = q.view(torch.float8_e4m3fn).float()             # the bytes ARE OCP e4m3
+    deq = (torch.nn.functional.pad(deq, (0, nb * 128 - K)).view(N, nb, 128) * s[:, :, None]).view(N, nb * 128)[:, :K]
+    err = (deq - w.float()).abs()
+    assert float((err / (wpad.abs().amax(dim=2)[:, :, None].expand(N, nb, 128).reshape(N, nb * 128)[:, :K] + 1e-30)).max()) <= 2.0 ** -4 + 1e-6
+    # the torch rounding of the same scaled values gives the same bytes (round-to-nearest-even, no saturation surprises)
+    q_ref = (wpad * (1.0 / s_ref)[:, :, None]).view(N, nb * 128)[:, :K].to(torch.float8_e4m3fn)
+    assert torch.equal(q.view(torch.float8_e4m3fn).float(), q_ref.float())
+    ref = x.float() @ deq.t()
+    got = ops.gemv_fp8w(x, (q, s), out_f32=True)
+    assert relerr(got, ref) < 2e-5
+    resid = rnd(M, N, dtype=dtype, seed=3)
+    assert relerr(ops.gemv_fp8w(x, (q, s), resid=resid), ref + resid.float()) < 3 * EPS16[dtype]

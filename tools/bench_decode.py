@@ -50,3 +50,18 @@ with torch.no_grad():
     ms = e0.elapsed_time(e1) / n
     print(json.dumps({"decode": "hip-graph", "B": B, "context": S, "ms_per_step": round(ms, 3), "tokens_per_s": round(B * 1e3 / ms, 1),
                       "hbm_gb_per_step": round((wbytes + cbytes) / 1e9, 2), "hbm_tb_s": round((wbytes + cbytes) / ms / 1e9, 2)}), flush=True)
+    # fp8 weights (e4m3, per-128-block scales), graph replay
+    model.engine.quantize_decode_weights()
+    g8, gtok8, glog8 = model.engine.capture_decode_graph(cache, fp8=True)
+    gtok8.copy_(tok)
+    for _ in range(3):
+        g8.replay(); gtok8.copy_(glog8.argmax(-1))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        g8.replay(); gtok8.copy_(glog8.argmax(-1))
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    w8 = wbytes // 2 + wbytes // 2 // 64  # fp8 bytes + fp32 scales (1 per 128)
+    print(json.dumps({"decode": "hip-graph fp8 weights", "B": B, "context": S, "ms_per_step": round(ms, 3), "tokens_per_s": round(B * 1e3 / ms, 1),
+                      "hbm_gb_per_step": round((w8 + cbytes) / 1e9, 2), "hbm_tb_s": round((w8 + cbytes) / ms / 1e9, 2)}), flush=True)

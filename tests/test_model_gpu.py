@@ -137,17 +137,22 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype):
     print(f"[full cfg1 {dtype}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
 
 
-def test_medium_backward_grad_norms_vs_reference_golden():
-    """Gradient digests (norm + strided sample) of every parameter vs the reference's (medium golden)."""
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_medium_backward_grad_norms_vs_reference_golden(dtype):
+    """Gradient digests (norm + strided sample) of every parameter vs the reference's (medium golden).
+    fp16: every sampled cosine >= 0.999 and norms within 1 % - the strict check of the backward maths.
+    bf16 (8x coarser mantissa): cosine >= 0.99, norms within 5 %; the 512-element strided sample of lm_head's gradient is
+    the exception: it consists of non-label vocabulary rows whose entries are sums of ~33 softmax probabilities
+    p ~ 3e-5, and bf16 logit noise (|d logit| ~ 0.1) moves each p by ~10 %, so that sample's cosine is noise-limited
+    (measured 0.86-0.96 depending on rounding details upstream; 0.9999 in fp16) - only its norm is pinned tightly."""
     from oracle import cases as C
 
-    dtype = torch.bfloat16
-    tol = TOL[dtype]
     cfg, batch = C.get_case("medium_cfg1")
     g = np.load(os.path.join(GOLD, "medium_cfg1.npz"))
     model = _build(cfg, dtype)
     out = model(**_to_dev(batch))
     out.loss.backward()
+    strict = dtype == torch.float16
     bad = []
     n = 0
     for k, p in model.named_parameters():
@@ -161,11 +166,11 @@ def test_medium_backward_grad_norms_vs_reference_golden():
         cos = float(samp @ ref / max(1e-30, np.linalg.norm(samp) * np.linalg.norm(ref)))
         ratio = float(f.double().norm()) / float(g[key])
         n += 1
-        # the 512-element strided sample of lm_head's gradient is made of non-label vocabulary rows whose
-        # entries are sums of ~33 softmax probabilities p ~ 3e-5: bf16 logit noise (|d logit| <= 0.1) moves each
-        # p by several %, so its sampled cosine is looser; the full-tensor norm (label rows) stays within 5%.
-        cmin = 0.95 if k == "lm_head.weight" else 0.99
-        if cos < cmin or abs(ratio - 1) > 0.05:
+        if strict:
+            cmin, rtol = 0.999, 0.01
+        else:
+            cmin, rtol = (0.80 if k == "lm_head.weight" else 0.99), 0.05
+        if cos < cmin or abs(ratio - 1) > rtol:
             bad.append((k, cos, ratio))
     assert n > 30
     assert not bad, bad[:8]

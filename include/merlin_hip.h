@@ -92,6 +92,14 @@ int mh_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* Wgu, int64_t ldw,
                        int M, int ff, int K, int dt, void* stream);
 int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, int64_t ldw, const void* gu, int64_t ldgu, void* dgu,
                        int64_t lddgu, int M, int ff, int K, int dt, void* stream);
+/* fp8 GEMM (forward / inference form of BASELINE cfg 5's "fp8 MFMA weight path"): both operands OCP e4m3 bytes with ONE
+ * fp32 scale per row (activation row = token, weight row = output channel), products on the gfx950 scaled-fp8 MFMA
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, hardware block scales 1.0), fp32 accumulate, C[m,n] = sa[m] sb[n] sum_k qa qb (+ the
+ * usual epilogue) in `dt_out`.  mh_quant_fp8_rows produces (q, scales) from a 16-bit matrix: scale = max|row| / 448.
+ * K % 128 == 0; lda, ldb in bytes, % 16 == 0. */
+int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scales, int R, int K, int dt, void* stream);
+int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C, int64_t ldc,
+                const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out, int epilogue, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,

@@ -229,6 +229,80 @@ extern "C" int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, 
   return gemm_impl(dy, lddy, 0, Wd, ldw, 1, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt, 0, 1, 0, stream, r);
 }
 
+// ---- fp8 operands (e4m3 bytes, one fp32 scale per row of A and per row of B), scaled-fp8 MFMA ------------------------
+namespace {
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_rows_k(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                        int64_t ldq, float* __restrict__ sc, int R, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const uint4* xr = (const uint4*)(x + (int64_t)row * ldx);
+  const int nch = K >> 3;
+  float mx = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+  }
+  mx = wave_max(mx);
+  const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) sc[row] = s;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
+    *(uint2*)(q + (int64_t)row * ldq + c * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+  }
+}
+}  // namespace
+
+extern "C" int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scales, int R, int K, int dt, void* stream) {
+  if (!x || !q || !scales || R <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 7) || !aligned16(x) || (((uintptr_t)q) & 7u)) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const dim3 grid((R + 3) / 4), block(256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(quant_fp8_rows_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, ldx, (uint8_t*)q, ldq, scales, R, K);
+  else
+    hipLaunchKernelGGL(quant_fp8_rows_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, ldx, (uint8_t*)q, ldq, scales, R, K);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+                           int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
+                           int epilogue, void* stream) {
+  if (!A8 || !B8 || !sa || !sb || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
+  if ((K % 128) || (lda & 15) || (ldb & 15) || !aligned16(A8) || !aligned16(B8)) return MH_ERR_ARG;
+  if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
+  if ((epilogue & MH_EPI_RESIDUAL) && !resid) return MH_ERR_ARG;
+  if (dt_out != MH_BF16 && dt_out != MH_F16) return MH_ERR_DTYPE;
+  GemmArgs g;
+  g.A = (const uint16_t*)A8; g.B = (const uint16_t*)B8; g.C = C;
+  g.bias = (const uint16_t*)bias; g.resid = (const uint16_t*)resid;
+  g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldr = ldr;   // 2-byte units: a 128-byte LDS row = 128 k
+  g.M = M; g.N = N; g.K = K / 2; g.epi = epilogue;
+  const bool f32out = epilogue & MH_EPI_OUT_F32;
+  g.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)C) & (f32out ? 15u : 7u)) == 0) &&
+             (!(epilogue & MH_EPI_RESIDUAL) || ((ldr % 4 == 0) && ((((uintptr_t)resid) & 7u) == 0))) &&
+             (!(epilogue & MH_EPI_BIAS) || ((((uintptr_t)bias) & 7u) == 0));
+  g.splits = 1; g.c_split = 0;
+  g.rope_tab = nullptr; g.rope_S = g.rope_D = g.rope_cols = 0;
+  g.sw_mode = 0; g.sw_ff = 0; g.sw_out = nullptr; g.sw_in = nullptr; g.sw_ldo = g.sw_ldi = 0;
+  g.sc_m = sa; g.sc_n = sb;
+  {
+    static void* zp = nullptr;
+    if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
+    g.zero_row = (const uint16_t*)zp;
+  }
+  g.tiles_m = (M + 255) / 256;
+  g.tiles_n = (N + 255) / 256;
+  return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
+}
+
 extern "C" int mh_gemm_splitk_max(int M, int N, int K) {
   const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
   const int nk = (K + BK - 1) / BK;
@@ -278,6 +352,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split;
+  g.sc_m = nullptr; g.sc_n = nullptr;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;
   {

@@ -102,17 +102,33 @@ __device__ __forceinline__ void read_frags_tr(FR& fr, const unsigned* at) {
     DSR(bf[0][0], aB0, BASE + 0);    DSR(bf[0][1], aB1, BASE + 0);                          \
     DSR(bf[1][0], aB0, BASE + 2048); DSR(bf[1][1], aB1, BASE + 2048);                       \
   } while (0)
+// fp8 operands (F8): a 128-byte LDS row holds 128 k instead of 64, and the two 16-byte pieces a lane reads per row
+// (chunks kq and 4 + kq) are exactly the 32 bytes v_mfma_scale_f32_16x16x128_f8f6f4 wants from lane group kq (layout and
+// rate probed in tools/probes/f8f6f4_probe.py): one MFMA per accumulator tile and K-tile, same bytes per phase, twice
+// the k.  Hardware block scales are left at 1.0; per-row scales are applied to the accumulators after the loop.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t mfma_f8(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4_t c) {
+  const i32x8_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+  const i32x8_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+}
 #define MFMA_QUAD(MH, NH, bf)                                                               \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+    if constexpr (F8) {                                                                     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
-          acc[MH][i][NH][j] = mfma16v<DT>(bf[j][ks], af[i][ks], acc[MH][i][NH][j]);         \
+          acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j]); \
+    } else {                                                                                \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                     \
+            acc[MH][i][NH][j] = mfma16v<DT>(bf[j][ks], af[i][ks], acc[MH][i][NH][j]);       \
+    }                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
 
-template <int DT, bool AKS, bool BKS>
+template <int DT, bool AKS, bool BKS, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by value: the split-K block offsets its own copy)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -259,6 +275,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   }
   if (wm == 0) MH_BAR();
   MH_WAIT_VM(0);  // drain the (redundant) tail loads before the block's LDS is released
+  if constexpr (F8) {  // C[m, n] = sc_m[m] * sc_n[n] * sum_k qa[m, k] qb[n, k]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float sm = g.sc_m[min(m0 + a * 128 + wm * 64 + i * 16 + (lane & 15), g.M - 1)];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] *= sm * g.sc_n[min(n + r, g.N - 1)];
+          }
+      }
+  }
 
   // Staged epilogue (16-bit C, vectorisable layout): the accumulator layout gives a lane 4 consecutive n of one
   // row, i.e. 32-byte pieces of 16 different rows per store instruction (measured: several microseconds per
@@ -426,5 +458,20 @@ int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, h
 }
 
 int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream) { return launch_gemm_256(g, dt, 0, 0, stream); }
+
+template <int DT>
+int launch_f8(const GemmArgs& g, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_256<DT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256, stream, g);
+  MH_LAUNCH_CHECK();
+}
+// fp8 operands: g.A / g.B point at bytes, g.K, g.lda, g.ldb are in 2-BYTE units (K/2 etc.), dt = output type
+int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream) {
+  return dt == MH_BF16 ? launch_f8<MH_BF16>(g, stream) : launch_f8<MH_F16>(g, stream);
+}
 
 }  // namespace mhgemm

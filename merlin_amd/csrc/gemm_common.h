@@ -23,6 +23,8 @@ struct GemmArgs {
   // + the 128 up columns ff + [n0, n0+128) (B rows taken from both halves of the fused weight); C = gu [M, 2 ff] is
   // written as usual and sw_out = act [M, ff] = silu(gate) * up.  sw_mode 2 (backward, dact = dY Wd): the tile of dact is
   // never stored; sw_out = dgu [M, 2 ff] from sw_in = gu [M, 2 ff].
+  const float* sc_m;  // fp8 operand form: per-row scales of A [M] and B [N] (applied to the accumulators)
+  const float* sc_n;
   int sw_mode, sw_ff;
   void* sw_out;
   const void* sw_in;
@@ -221,6 +223,7 @@ int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream);
 // operand layouts: K-contiguous (0) or K-strided (1), see gemm256.hip
 int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
 int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0);      // gemm256w4.hip (4 waves x 128x128)
+int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA
 int launch_gemm_nt_w8(const GemmArgs& g, int dt, hipStream_t stream);      // gemm256w8.hip (8 waves, dense asm stream)
 int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)
 

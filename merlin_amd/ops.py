@@ -251,6 +251,37 @@ def gemm_swiglu_bwd(dy, wd, gu):
     return dgu
 
 
+def quant_fp8_rows(x):
+    """x [R, K] (16-bit) -> (q uint8 [R, K] OCP e4m3, scales fp32 [R]): one scale per row."""
+    R, K = x.shape
+    q = torch.empty(R, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(R, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mh_quant_fp8_rows(p(x), i64(_rowmajor(x)), p(q), i64(K), p(sc), i32(R), i32(K), i32(dt_of(x)), _stream()), "mh_quant_fp8_rows")
+    return q, sc
+
+
+def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None):
+    """out[M, N] = (sa qa) @ (sb qb)^T on the scaled-fp8 MFMA; a8 = (qa [M, K] uint8, sa [M]), b8 = (qb [N, K], sb [N])."""
+    (qa, sa), (qb, sb) = a8, b8
+    M, K = qa.shape
+    N = qb.shape[0]
+    assert qb.shape[1] == K
+    out = torch.empty(M, N, dtype=out_dtype, device=qa.device) if out is None else out
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+    if act == "quick_gelu":
+        epi |= EPI_QUICK_GELU
+    ldr = 0
+    if resid is not None:
+        epi |= EPI_RESIDUAL
+        ldr = _rowmajor(resid)
+    with _timed("gemm_fp8", 2.0 * M * N * K):
+        L.check(L.lib().mh_gemm_fp8(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(out), i64(_rowmajor(out)), p(bias),
+                                    p(resid), i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(out)), i32(epi), _stream()), "mh_gemm_fp8")
+    return out
+
+
 def transpose16(x, r_pad=None, out=None):
     """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
     R, Cc = x.shape

@@ -646,3 +646,27 @@ def test_fp8_block_quant_and_gemv(ops, dtype, M, N, K):
     assert relerr(got, ref) < 2e-5
     resid = rnd(M, N, dtype=dtype, seed=3)
     assert relerr(ops.gemv_fp8w(x, (q, s), resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 384), (1000, 520, 256), (613, 4096, 1024), (4096, 4096, 4096), (300, 104, 128)])
+def test_gemm_fp8_scaled_mfma(ops, dtype, M, N, K):
+    """fp8 x fp8 GEMM on the gfx950 scaled-fp8 MFMA (per-row scales): exact against the fp32 product of the DEQUANTISED
+    operands (only the summation order and the output rounding differ), within the format's error of the unquantised
+    product, bit-identical run to run, with bias / residual epilogues and ragged M, N."""
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    qa, qb = ops.quant_fp8_rows(a), ops.quant_fp8_rows(b)
+    da = qa[0].view(torch.float8_e4m3fn).float() * qa[1][:, None]
+    db = qb[0].view(torch.float8_e4m3fn).float() * qb[1][:, None]
+    assert torch.allclose(qa[1], a.float().abs().amax(dim=1) / 448.0, rtol=1e-6)
+    ref = da @ db.t()
+    out = ops.gemm_fp8(qa, qb, out_dtype=dtype)
+    assert relerr(out, ref) < 3 * EPS16[dtype]
+    for _ in range(2):
+        assert torch.equal(ops.gemm_fp8(qa, qb, out_dtype=dtype), out)
+    full = a.float() @ b.float().t()
+    assert relerr(out, full) < 5e-2                      # e4m3 with per-row scales: a few % of the output range
+    if N % 4 == 0:
+        bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
+        z = ops.gemm_fp8(qa, qb, out_dtype=dtype, bias=bias, resid=resid)
+        assert relerr(z, ref + bias.float() + resid.float()) < 4 * EPS16[dtype]

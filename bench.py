@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--recompute", action="store_true", help="recompute each layer's forward in backward (the reference's "
                     "gradient checkpointing) instead of keeping activations resident in the 288 GB of HBM")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--fp8-forward", action="store_true", help="with --fwd-only: decoder Linears on the scaled-fp8 MFMA (e4m3 operands, "
+                    "per-row scales); NOT the headline configuration (dtype field says so)")
     args = ap.parse_args()
     if os.environ.get("MH_GEMM_FORCE"):  # A/B arm selection for kernel development (see mh_gemm_force_kernel)
         from merlin_amd import ops as _O
@@ -120,6 +122,9 @@ def main():
     assert O.arch_ok(local_rank), "bench.py needs a gfx950 (MI355X) device"
     model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
     model.engine.save_activations = not args.recompute
+    if args.fp8_forward:
+        assert args.fwd_only, "--fp8-forward is forward-only"
+        model.fp8_forward = True
     if args.config == "cfg3":
         B = args.batch or 8
         batch = synth.interpair_batch(B=B, S=4096, rank=rank)
@@ -208,7 +213,7 @@ def main():
     line = {
         "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
                    "step": "fwd only" if args.fwd_only else "fwd+bwd" + (" (layer recompute)" if args.recompute else " (activations resident)") + "+allreduce+adamw",

@@ -385,6 +385,34 @@ class HipEngine:
         y = O.gemm_nt(act, W.wd, resid=x2)
         return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
 
+    def quantize_forward_weights(self):
+        """fp8 (e4m3, one scale per output channel) copies of the decoder's Linear weights for the fp8 FORWARD (inference /
+        prefill form of BASELINE cfg 5's fp8 MFMA weight path).  Re-run after the weights change."""
+        self.ensure_arena()
+        self._fp8_fwd = [dict(wqkv=O.quant_fp8_rows(W.wqkv), wo=O.quant_fp8_rows(W.wo), wgu=O.quant_fp8_rows(W.wgu),
+                              wd=O.quant_fp8_rows(W.wd)) for W in self.llama]
+        return self._fp8_fwd
+
+    def _llama_layer_fwd_fp8(self, W, Q, x, B, S, lens, kv_out=None):
+        """Decoder layer with every Linear on the scaled-fp8 MFMA: activations are quantised per token row right before
+        each GEMM (dynamic scaling), weights per output channel (once); residual stream, norms, RoPE, attention and
+        SwiGLU stay 16-bit.  Forward only."""
+        cfg = self.model.config
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        h1 = O.rmsnorm_fwd(x, W.ln1, eps)
+        qkv = O.gemm_fp8(O.quant_fp8_rows(h1), Q["wqkv"], out_dtype=x.dtype)
+        O.rope_qk_(qkv, self.rope, S, H, D)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        if kv_out is not None:
+            kv_out[0][:, :S].copy_(k.view(B, S, d))
+            kv_out[1][:, :S].copy_(v.view(B, S, d))
+        o, _ = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+        x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
+        h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+        act = O.swiglu_fwd(O.gemm_fp8(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype))
+        return O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
+
     def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
         A = self.arena
@@ -464,7 +492,7 @@ class HipEngine:
     # public entry points
     # ------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask, labels, images, inputs_embeds=None, want_grad=False, loss_only=False,
-                kv_cache=None, last_only=False):
+                kv_cache=None, last_only=False, fp8=False):
         """Returns (loss fp32 scalar tensor | None, logits fp32 [B,S,V] view | None, ctx)."""
         m = self.model
         cfg = m.config
@@ -508,7 +536,18 @@ class HipEngine:
         del feats
         # ---- decoder ----
         xs, saves = [], []
+        if fp8:
+            if want_grad:
+                raise RuntimeError("the fp8 GEMM path is forward-only (no backward through fp8 operands)")
+            if d % 128 or cfg.intermediate_size % 128:
+                raise RuntimeError("fp8 forward needs hidden and intermediate sizes that are multiples of 128")
+            F8 = getattr(self, "_fp8_fwd", None) or self.quantize_forward_weights()
         for li, W in enumerate(self.llama):
+            if fp8:
+                x = self._llama_layer_fwd_fp8(W, F8[li], x, B, S, lens,
+                                              kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None)
+                saves.append(None)
+                continue
             if want_grad:
                 xs.append(x)
             x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations,

@@ -197,9 +197,10 @@ class MMGPTLlamaForCausalLM(nn.Module):
         if not self.use_im_start_end and images is not None:
             raise NotImplementedError  # base_mmgpt.py:137
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters())
+        fp8 = bool(getattr(self, "fp8_forward", False))  # opt-in: model.fp8_forward = True (forward / inference only)
         with torch.no_grad():
             loss, logits, ectx = self.engine.forward(input_ids, attention_mask, labels, images, inputs_embeds=inputs_embeds,
-                                                     want_grad=want_grad)
+                                                     want_grad=want_grad, fp8=fp8)
         if want_grad:
             if self._anchor is None or self._anchor.device != loss.device:
                 self._anchor = torch.zeros(1, device=loss.device, requires_grad=True)

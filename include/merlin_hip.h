@@ -100,6 +100,11 @@ int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, int64_t ldw
 int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scales, int R, int K, int dt, void* stream);
 int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C, int64_t ldc,
                 const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out, int epilogue, void* stream);
+/* fp8 forms of mh_gemm_nt_rope and mh_gemm_swiglu_fwd (the same fused store phases behind the fp8 product). */
+int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C, int64_t ldc,
+                     int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols, void* stream);
+int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* gu,
+                           int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,

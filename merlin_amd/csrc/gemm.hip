@@ -272,9 +272,38 @@ extern "C" int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ld
   MH_LAUNCH_CHECK();
 }
 
+static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+                         int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
+                         int epilogue, const RopeSpec& fx, void* stream);
+
 extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
                            int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
                            int epilogue, void* stream) {
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, C, ldc, bias, resid, ldr, M, N, K, dt_out, epilogue, RopeSpec(), stream);
+}
+// fp8 forms of mh_gemm_nt_rope / mh_gemm_swiglu_fwd (same staged store phases)
+extern "C" int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+                                int64_t ldc, int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols,
+                                void* stream) {
+  if (!cos_sin || S <= 0 || (D != 128 && D != 64) || rope_cols <= 0 || rope_cols > N || (rope_cols % D) || (N & 7) || (ldc & 7) ||
+      ((((uintptr_t)C) & 15u) != 0))
+    return MH_ERR_ARG;
+  RopeSpec r;
+  r.tab = cos_sin; r.S = S; r.D = D; r.cols = rope_cols;
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, C, ldc, nullptr, nullptr, 0, M, N, K, dt_out, 0, r, stream);
+}
+extern "C" int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb,
+                                      void* gu, int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out,
+                                      void* stream) {
+  if (!gu || !act || ff <= 0 || (ff & 7) || (ldgu & 7) || (ldact & 7) || ((((uintptr_t)gu) | ((uintptr_t)act)) & 15u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 1; r.sw_ff = ff; r.sw_out = act; r.sw_ldo = ldact;
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, gu, ldgu, nullptr, nullptr, 0, M, 2 * ff, K, dt_out, 0, r, stream);
+}
+
+static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+                         int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
+                         int epilogue, const RopeSpec& fx, void* stream) {
   if (!A8 || !B8 || !sa || !sb || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
   if ((K % 128) || (lda & 15) || (ldb & 15) || !aligned16(A8) || !aligned16(B8)) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
@@ -290,8 +319,8 @@ extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const v
              (!(epilogue & MH_EPI_RESIDUAL) || ((ldr % 4 == 0) && ((((uintptr_t)resid) & 7u) == 0))) &&
              (!(epilogue & MH_EPI_BIAS) || ((((uintptr_t)bias) & 7u) == 0));
   g.splits = 1; g.c_split = 0;
-  g.rope_tab = nullptr; g.rope_S = g.rope_D = g.rope_cols = 0;
-  g.sw_mode = 0; g.sw_ff = 0; g.sw_out = nullptr; g.sw_in = nullptr; g.sw_ldo = g.sw_ldi = 0;
+  g.rope_tab = fx.tab; g.rope_S = fx.S; g.rope_D = fx.D; g.rope_cols = fx.cols;
+  g.sw_mode = fx.sw_mode; g.sw_ff = fx.sw_ff; g.sw_out = fx.sw_out; g.sw_in = fx.sw_in; g.sw_ldo = fx.sw_ldo; g.sw_ldi = fx.sw_ldi;
   g.sc_m = sa; g.sc_n = sb;
   {
     static void* zp = nullptr;
@@ -299,7 +328,7 @@ extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const v
     g.zero_row = (const uint16_t*)zp;
   }
   g.tiles_m = (M + 255) / 256;
-  g.tiles_n = (N + 255) / 256;
+  g.tiles_n = fx.sw_mode == 1 ? (fx.sw_ff + 127) / 128 : (N + 255) / 256;
   return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
 }
 

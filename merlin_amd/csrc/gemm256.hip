@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
+            const int n = (b ? nB1 : n0) + wn * 32 + j * 16 + 4 * (lane >> 4);  // (fused SwiGLU: the second half-tile is the up rows)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] *= sm * g.sc_n[min(n + r, g.N - 1)];
           }

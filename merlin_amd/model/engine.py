@@ -401,8 +401,7 @@ class HipEngine:
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         eps = cfg.rms_norm_eps
         h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-        qkv = O.gemm_fp8(O.quant_fp8_rows(h1), Q["wqkv"], out_dtype=x.dtype)
-        O.rope_qk_(qkv, self.rope, S, H, D)
+        qkv = O.gemm_fp8_rope(O.quant_fp8_rows(h1), Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         if kv_out is not None:
             kv_out[0][:, :S].copy_(k.view(B, S, d))
@@ -410,7 +409,7 @@ class HipEngine:
         o, _ = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-        act = O.swiglu_fwd(O.gemm_fp8(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype))
+        _, act = O.gemm_fp8_swiglu_fwd(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype)
         return O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
 
     def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):

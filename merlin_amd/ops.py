@@ -282,6 +282,31 @@ def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, 
     return out
 
 
+def gemm_fp8_rope(a8, b8, table, S, H, D, out_dtype=torch.bfloat16):
+    """fp8 q|k|v projection with RoPE in the epilogue (see gemm_nt_rope)."""
+    (qa, sa), (qb, sb) = a8, b8
+    M, K = qa.shape
+    N = qb.shape[0]
+    out = torch.empty(M, N, dtype=out_dtype, device=qa.device)
+    with _timed("gemm_fp8", 2.0 * M * N * K):
+        L.check(L.lib().mh_gemm_fp8_rope(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(out), i64(N), i32(M), i32(N),
+                                         i32(K), i32(dt_of(out)), p(table), i32(S), i32(D), i32(2 * H * D), _stream()), "mh_gemm_fp8_rope")
+    return out
+
+
+def gemm_fp8_swiglu_fwd(a8, b8, out_dtype=torch.bfloat16):
+    """fp8 gate|up projection with SwiGLU in the epilogue (see gemm_swiglu_fwd).  Returns (gu, act)."""
+    (qa, sa), (qb, sb) = a8, b8
+    M, K = qa.shape
+    ff = qb.shape[0] // 2
+    gu = torch.empty(M, 2 * ff, dtype=out_dtype, device=qa.device)
+    act = torch.empty(M, ff, dtype=out_dtype, device=qa.device)
+    with _timed("gemm_fp8", 2.0 * M * 2 * ff * K):
+        L.check(L.lib().mh_gemm_fp8_swiglu_fwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(gu), i64(2 * ff), p(act),
+                                               i64(ff), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()), "mh_gemm_fp8_swiglu_fwd")
+    return gu, act
+
+
 def transpose16(x, r_pad=None, out=None):
     """x[R, C] (16-bit) -> out[C, R_pad] with zero-filled tail columns."""
     R, Cc = x.shape

@@ -670,3 +670,23 @@ def test_gemm_fp8_scaled_mfma(ops, dtype, M, N, K):
         bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
         z = ops.gemm_fp8(qa, qb, out_dtype=dtype, bias=bias, resid=resid)
         assert relerr(z, ref + bias.float() + resid.float()) < 4 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_fp8_fused_rope_and_swiglu_match_unfused(ops, dtype):
+    """The fp8 GEMM shares the staged store phases of the 16-bit kernel: RoPE / SwiGLU fused behind the fp8 product must be
+    bit-identical to the fp8 GEMM followed by the stand-alone kernels."""
+    B, S, H, D, K = 2, 200, 2, 128, 256
+    T, d = B * S, H * D
+    x, w = rnd(T, K, dtype=dtype), rnd(3 * d, K, dtype=dtype, seed=1, scale=0.5)
+    qx, qw = ops.quant_fp8_rows(x), ops.quant_fp8_rows(w)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    ref = ops.gemm_fp8(qx, qw, out_dtype=dtype)
+    ops.rope_qk_(ref, tab, S, H, D)
+    assert torch.equal(ops.gemm_fp8_rope(qx, qw, tab, S, H, D, out_dtype=dtype), ref)
+    ff = 640
+    wgu = rnd(2 * ff, K, dtype=dtype, seed=2, scale=0.5)
+    qg = ops.quant_fp8_rows(wgu)
+    gu_ref = ops.gemm_fp8(qx, qg, out_dtype=dtype)
+    gu, act = ops.gemm_fp8_swiglu_fwd(qx, qg, out_dtype=dtype)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, ops.swiglu_fwd(gu_ref))

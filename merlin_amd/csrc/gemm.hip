@@ -409,10 +409,15 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
-    g.tiles_m = (M + 255) / 256;
-    g.tiles_n = (N + 255) / 256;
-    return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
+  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode &&
+      (int64_t)M * lda * 2 < (1ll << 31) && (int64_t)N * ldb * 2 < (1ll << 31)) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
+    const int e = epilogue;
+    const bool known = e == 0 || e == MH_EPI_RESIDUAL || e == MH_EPI_BIAS || e == (MH_EPI_BIAS | MH_EPI_QUICK_GELU) || e == (MH_EPI_BIAS | MH_EPI_RESIDUAL);
+    if (known && g.vec_ok && (N % 8 == 0) && (ldc % 8 == 0) && ((((uintptr_t)C) & 15u) == 0)) {  // staged epilogue only
+      g.tiles_m = (M + 255) / 256;
+      g.tiles_n = (N + 255) / 256;
+      return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
+    }
   }
   if (g_force_kernel == 88 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode &&
       (int64_t)M * lda * 2 < (1ll << 31) && (int64_t)N * ldb * 2 < (1ll << 31)) {  // A/B arm: 8 waves, dense stream (gemm256w8.hip)

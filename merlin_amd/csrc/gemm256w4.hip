@@ -284,15 +284,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4(GemmArgs g) {
     }
     return;
   }
-  epi_dispatch<DT>(g, [&](auto store) {
-    w4_static_for<64>([&](auto T) {
-      constexpr int t = decltype(T)::value, i = t / 8, j = t % 8;
-      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-      const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
-      const f32x4_t v = acc[i][j];
-      store(m, n, v[0], v[1], v[2], v[3]);
-    });
-  });
+  // (no generic fallback here: the host routes only staged-epilogue cases to this kernel - 64 inlined generic stores per
+  // thread took 12 minutes to compile and spilled)
 }
 
 }  // namespace
@@ -308,8 +301,9 @@ int launch_w4(const GemmArgs& g, hipStream_t stream) {
   MH_LAUNCH_CHECK();
 }
 
-// var: 0 = the kernel; 1..3 = timing probes with wrong results (no copies / no fragment reads / no barrier)
+// var: 0 = the kernel; 1..8 = timing probes with wrong results (compiled only with -DMH_W4_PROBES: each is a full kernel)
 int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var) {
+#ifdef MH_W4_PROBES
   if (var == 1) return launch_w4<MH_BF16, 1>(g, stream);
   if (var == 2) return launch_w4<MH_BF16, 2>(g, stream);
   if (var == 3) return launch_w4<MH_BF16, 3>(g, stream);
@@ -318,6 +312,9 @@ int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var) {
   if (var == 6) return launch_w4<MH_BF16, 6>(g, stream);
   if (var == 7) return launch_w4<MH_BF16, 7>(g, stream);
   if (var == 8) return launch_w4<MH_BF16, 8>(g, stream);
+#else
+  if (var != 0) return MH_ERR_ARG;
+#endif
   return dt == MH_BF16 ? launch_w4<MH_BF16, 0>(g, stream) : launch_w4<MH_F16, 0>(g, stream);
 }
 

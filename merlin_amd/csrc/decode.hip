@@ -148,46 +148,94 @@ __device__ __forceinline__ void fp8x4_to_f32(uint32_t p, float* f) {
 
 // y[m, n] = sum_kb s[n, kb] * sum_{k in block} q[n, k] x[m, k] (+ resid): one wave per weight row, 16 fp8 (16 B) per lane
 // and step (a lane's 16 values lie inside one 128-block), fp32 accumulate.  K % 16 == 0.
-template <int DT, int MM>
+template <int DT, int MM, int ROWS, bool LDSX>
 __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ q,
                                                    const float* __restrict__ sc, void* __restrict__ out, int64_t ldo,
                                                    const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs8[];  // [MM][GEMV_KC] when LDSX (as in gemv_k)
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   const int nb = (K + 127) / 128;
-  float acc[MM];
+  float acc[ROWS][MM];
 #pragma unroll
-  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-  const uint8_t* qrow = q + (int64_t)n * K;
-  const float* srow = sc + (int64_t)n * nb;
-  for (int k0 = lane * 16; k0 < K; k0 += 1024) {
-    const uint4 qv = *(const uint4*)(qrow + k0);
-    const float s = srow[k0 >> 7];
-    float w[16];
-    fp8x4_to_f32(qv.x, w); fp8x4_to_f32(qv.y, w + 4); fp8x4_to_f32(qv.z, w + 8); fp8x4_to_f32(qv.w, w + 12);
+  for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int m = 0; m < MM; ++m) {
-      float xa[8], xb[8];
-      unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + k0), xa);
-      unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + k0 + 8), xb);
-      float p = 0.f;
+    for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const uint8_t* qrow[ROWS];
+  const float* srow[ROWS];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) p = fmaf(w[e], xa[e], p);
+  for (int r = 0; r < ROWS; ++r) {
+    const int n = min(n0 + r, N - 1);
+    qrow[r] = q + (int64_t)n * K;
+    srow[r] = sc + (int64_t)n * nb;
+  }
+  for (int kc = 0; kc < K; kc += GEMV_KC) {
+    const int klen = min(GEMV_KC, K - kc);
+    if constexpr (LDSX) {
+      if (kc) __syncthreads();
+      for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
+        const int m = i / klen, k = i - m * klen;
+        *(uint4*)(xs8 + m * GEMV_KC + k) = *(const uint4*)(x + (int64_t)m * ldx + kc + k);
+      }
+      __syncthreads();
+    }
+    if (n0 < N) {
+      for (int k0 = lane * 16; k0 < klen; k0 += 1024) {
+        uint4 qv[ROWS];
+        float s[ROWS];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) p = fmaf(w[8 + e], xb[e], p);
-      acc[m] = fmaf(s, p, acc[m]);
+        for (int r = 0; r < ROWS; ++r) {
+          qv[r] = *(const uint4*)(qrow[r] + kc + k0);
+          s[r] = srow[r][(kc + k0) >> 7];
+        }
+        float p[ROWS][MM];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int m = 0; m < MM; ++m) p[r][m] = 0.f;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {  // 8 values at a time keeps the dequantised weights of ROWS rows in 8*ROWS registers
+          float w[ROWS][8];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            fp8x4_to_f32(hlf ? qv[r].z : qv[r].x, w[r]);
+            fp8x4_to_f32(hlf ? qv[r].w : qv[r].y, w[r] + 4);
+          }
+#pragma unroll
+          for (int m = 0; m < MM; ++m) {
+            float xa[8];
+            if constexpr (LDSX) unpack8<DT>(*(const uint4*)(xs8 + m * GEMV_KC + k0 + 8 * hlf), xa);
+            else unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + kc + k0 + 8 * hlf), xa);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) p[r][m] = fmaf(w[r][e], xa[e], p[r][m]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int m = 0; m < MM; ++m) acc[r][m] = fmaf(s[r], p[r][m], acc[r][m]);
+      }
     }
   }
+  if (n0 >= N) return;
 #pragma unroll
-  for (int m = 0; m < MM; ++m) acc[m] = wave_sum(acc[m]);
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
   if (lane == 0) {
 #pragma unroll
-    for (int m = 0; m < MM; ++m) {
-      float v = acc[m];
-      if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
-      if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
-      else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        float v = acc[r][m];
+        if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+        if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+        else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+      }
     }
   }
 }
@@ -449,18 +497,33 @@ extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const flo
   if (!x || !q || !scales || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  const dim3 grid((N + 3) / 4), block(256);
+  const int rows = M < 3 ? 1 : (N >= 8192 ? 2 : 1);  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv)
+  const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
   hipStream_t st = as_stream(stream);
-#define GO(DT_, MM_)                                                                                                         \
-  hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_>), grid, block, 0, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, \
-                     (const uint16_t*)resid, ldr, N, K, out_f32)
+#define GO(DT_, MM_, R_, L_)                                                                                                       \
+  do {                                                                                                                              \
+    const size_t lds_ = L_ ? (size_t)MM_ * GEMV_KC * 2 : 0;                                                                         \
+    static bool attr_ = false;                                                                                                      \
+    if (L_ && !attr_) {                                                                                                             \
+      hipFuncSetAttribute((const void*)gemv_fp8w_k<DT_, MM_, R_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);       \
+      attr_ = true;                                                                                                                 \
+    }                                                                                                                               \
+    hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_, R_, L_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, \
+                       out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);                                                      \
+  } while (0)
+#define GOR(DT_, MM_)                                                                        \
+  do {                                                                                       \
+    if (rows == 2) GO(DT_, MM_, 2, true); else GO(DT_, MM_, 1, true);                       \
+  } while (0)
 #define GOM(DT_)                                                                                                   \
   switch (M) {                                                                                                     \
-    case 1: GO(DT_, 1); break; case 2: GO(DT_, 2); break; case 3: GO(DT_, 3); break; case 4: GO(DT_, 4); break;   \
-    case 5: GO(DT_, 5); break; case 6: GO(DT_, 6); break; case 7: GO(DT_, 7); break; default: GO(DT_, 8); break;   \
+    case 1: GO(DT_, 1, 1, false); break; case 2: GO(DT_, 2, 1, false); break; case 3: GOR(DT_, 3); break;         \
+    case 4: GOR(DT_, 4); break; case 5: GOR(DT_, 5); break; case 6: GOR(DT_, 6); break;                           \
+    case 7: GOR(DT_, 7); break; default: GOR(DT_, 8); break;                                                       \
   }
   if (dt == MH_BF16) { GOM(MH_BF16); } else { GOM(MH_F16); }
 #undef GOM
+#undef GOR
 #undef GO
   MH_LAUNCH_CHECK();
 }

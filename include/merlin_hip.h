@@ -151,36 +151,18 @@ int mh_rope_table(float* cos_sin, int S, int D, float theta, void* stream); /* [
 int mh_rope_qk(void* qkv, const float* cos_sin, int T, int S, int H, int D, int inverse, int dt, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------- */
-/* vt[b, h, d, perm(s)] = qkv[(b*S + s), which=2, h, d]; S_pad = round_up(S, 64); perm swaps
- * bits 2 and 3 of s (the MFMA k-slot order the attention kernels use). Tail is zero filled. */
-int mh_attn_prep_v(const void* v, int64_t ldv, void* vt, int B, int S, int H, int D, int dt, void* stream);
-/* Flash attention forward.  q/k are [B*S, H, D] views with row stride ldq/ldk (elements);
- * vt from mh_attn_prep_v; o is [B*S, H*D] (ldo); lse fp32 [B, H, S_pad].  seqlens int32[B] or null
- * (= S): keys >= seqlens[b] are excluded and query rows >= seqlens[b] are written as zeros,
+/* Flash attention forward.  q/k/v are [B*S, H, D] views with row strides ldq/ldk/ldv (elements): V is taken ROW-MAJOR and
+ * transposed on the fly by LDS transpose-reads; o is [B*S, H*D] (ldo); lse fp32 [B, H, S_pad], S_pad = round_up(S, 64).
+ * seqlens int32[B] or null (= S): keys >= seqlens[b] are excluded and query rows >= seqlens[b] are written as zeros,
  * i.e. flash_attn_varlen + pad_input semantics (llama_flash_attn_monkey_patch.py:87-102).
  * causal=1: Llama (D=128), causal=0: CLIP (D=64).  scale = 1/sqrt(D). */
-int mh_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, void* o, int64_t ldo,
-                float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
-/* Forward v2: identical semantics, but V is taken ROW-MAJOR (v: [B*S, H, D] view, row stride ldv) and transposed on the
- * fly by LDS transpose-reads: no mh_attn_prep_v pass. */
 int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                  float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
-/* Backward v2: same contract as mh_attn_bwd but no workspace and no operand re-layout passes (transposed operands
- * come from LDS transpose-reads).  `delta`: ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats. */
+/* Backward: dq/dk/dv are [B*S, H, D] views with their own row strides; no workspace and no operand re-layout passes
+ * (transposed operands come from LDS transpose-reads); rope_cos_sin != NULL applies the inverse RoPE to dq, dk.  `delta`: ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats. */
 int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                  const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
                  void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt, void* stream);
-/* Backward: `delta` is a ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats (rowsum(dO*O), then lse*log2e).
- * dq/dk/dv are [B*S, H, D] views with their own row strides.  v is the ROW-MAJOR v (not vt).
- * ws: 16-bit workspace of mh_attn_bwd_ws_elems() elements (holds Q^T, dO^T, K^T re-layouts). */
-int64_t mh_attn_bwd_ws_elems(int B, int S, int H, int D);
-/* A/B switch for benchmarks: 1 (default) = separate dV and dK launches (lean kernels), 0 = one fused launch */
-void mh_attn_bwd_split(int split);
-int mh_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta,
-                void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* ws,
-                const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
-
 /* ---- KV-cache decode (S_q = 1): generate() behind llama_mmgpt.py:114-134 / eval_mmvet.py:101-120 ------------------
  * HF LlamaAttention with past_key_values (modeling_llama.py:243-281): q,k of the new token rotated at its own
  * position, k,v appended to the cache, softmax(q K^T / sqrt(D)) V over keys [0, len).  All HBM-bound kernels. */
@@ -206,11 +188,17 @@ int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, const void* v
                    int B, int H, int D, int Smax, float* ws, int dt, void* stream);
 
 /* ---- CLIP patch embedding ------------------------------------------------------------- */
-/* cols[n*G*G + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad.
- * pixels fp32 (pix_dt = MH_F32) or 16-bit; cols `dt`.  clip_encoder.py:76-79 -> CLIPVisionEmbeddings. */
-int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img, int ps, int Kpad, int dt, void* stream);
-/* x[n, 0, :] = cls + pos[0];  x[n, 1+p, :] = patch[n*G2 + p, :] + pos[1+p]   (then pre_layrnorm) */
+/* cols[n*rows_per_img + row0 + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad; the
+ * first row0 rows of every image (the CLS slot when rows_per_img = G*G+1, row0 = 1) are zero, so the token-major layout
+ * of the tower is used from the first GEMM on and the patch-embedding weight gradient is ONE K-strided GEMM over all
+ * rows.  pixels fp32 (pix_dt = MH_F32) or 16-bit; cols `dt`.  clip_encoder.py:76-79 -> CLIPVisionEmbeddings. */
+int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img, int ps, int Kpad, int rows_per_img, int row0,
+                      int dt, void* stream);
+/* x[n, 0, :] = cls + pos[0];  x[n, 1+p, :] = patch[n*(G2+1) + 1 + p, :] + pos[1+p]   (then pre_layrnorm) */
 int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x, int N, int G2, int d, int dt, void* stream);
+/* dst[r, c] (=|+=) src[r, c], r < rows, c < cols: strided 2-D block copy / accumulate of 16-bit data (pads the
+ * patch-embedding weight's K = 588 to 640 once per weight version and un-pads its gradient) */
+int mh_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int accumulate, int dt, void* stream);
 /* backward of assemble: dpatch rows copy, dcls/dpos partial sums are taken with mh_colsum */
 
 /* ---- ConvProjector (conv_projector.py:23-39): Conv2d(C->d, k3, stride s, pad 1) as an implicit GEMM -------------
@@ -234,6 +222,14 @@ int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src,
 /* lens[b] = 1 + last s with mask[b, s] != 0 (mask: bool/uint8 [B, S]); the collator's right-padded
  * attention_mask (collator.py:32) -> per-sample lengths = flash-attn's cu_seqlens */
 int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream);
+/* Device-side validation of a batch (no host sync; the caller reads `err` back asynchronously):
+ *   err[4]/err[5]: an input id outside [0, V) / its flat position      (reference: torch embedding raises IndexError)
+ *   err[6]/err[7]: a label that is neither -100 nor in [0, V) / position (reference: CrossEntropyLoss target out of bounds)
+ *   err[8]/err[9]: attention_mask of sample err[9] is not a right-padded prefix (popcount != lens[b]); this path implements
+ *   the key-padding form of llama_flash_attn_monkey_patch.py:87-102 for right-padded batches (collator.py:29-34) only.
+ * ids / labels / mask may each be NULL (skipped).  err is int32[10], shared with mh_splice_index (slots 0-3). */
+int mh_check_inputs(const int64_t* ids, const int64_t* labels, const void* mask_u8, const int32_t* lens, int32_t* err, int B, int S,
+                    int V, void* stream);
 int mh_embed_splice_fwd(const int64_t* ids, const int32_t* src, const void* embed, const void* feats,
                         void* out, int T, int d, int dt, void* stream);
 /* dfeats[src] = dout rows (pure copy; rows never collide); dembed32[ids] += dout (fp32 atomics) */

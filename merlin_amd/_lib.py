@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmerlin_hip.so")
+# MH_LIB_PATH: kernel-development override (tools/dev_arms/libmerlin_hip_dev.so = product kernels + A/B arms)
+LIB_PATH = os.environ.get("MH_LIB_PATH") or os.path.join(_HERE, "csrc", "libmerlin_hip.so")
 HEADER = os.path.join(_HERE, "..", "include", "merlin_hip.h")
 
 MH_BF16, MH_F16, MH_F32 = 0, 1, 2
@@ -41,7 +42,8 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.mh_strerror.restype = C.c_char_p
         _lib.mh_strerror.argtypes = [C.c_int]
-        _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
+        if hasattr(_lib, "mh_attn_bwd_ws_elems"):  # dev library only
+            _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
     return _lib
 
 

@@ -151,16 +151,18 @@ __global__ __launch_bounds__(256) void rope_qk_k(uint16_t* __restrict__ qkv, con
 // ---- CLIP patch embedding helpers -----------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void im2col_k(const void* __restrict__ pix, int pix_dt, uint16_t* __restrict__ cols,
-                                                int N, int img, int ps, int Kpad) {
+                                                int N, int img, int ps, int Kpad, int rpi, int row0) {
+  // image n owns rows [n*rpi, (n+1)*rpi): rows below row0 (the CLS slot) are zero, patch p sits at row n*rpi + row0 + p
   const int G = img / ps, K = 3 * ps * ps;
-  const int64_t total = (int64_t)N * G * G * Kpad;
+  const int64_t total = (int64_t)N * rpi * Kpad;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int k = (int)(i % Kpad);
     const int64_t row = i / Kpad;
+    const int t = (int)(row % rpi) - row0;
     float v = 0.f;
-    if (k < K) {
-      const int p = (int)(row % (G * G));
-      const int n = (int)(row / (G * G));
+    if (k < K && t >= 0 && t < G * G) {
+      const int p = t;
+      const int n = (int)(row / rpi);
       const int c = k / (ps * ps), rem = k - c * ps * ps, py = rem / ps, px = rem - py * ps;
       const int gy = p / G, gx = p - gy * G;
       v = load_any(pix, pix_dt, (((int64_t)n * 3 + c) * img + gy * ps + py) * img + gx * ps + px);
@@ -174,20 +176,35 @@ template <int DT>
 __global__ __launch_bounds__(256) void vit_assemble_k(const uint16_t* __restrict__ patch, const uint16_t* __restrict__ cls,
                                                       const uint16_t* __restrict__ pos, uint16_t* __restrict__ x, int N,
                                                       int G2, int d) {
+  // patch rows are laid out like x: [N, G2 + 1, d] with an (ignored) CLS slot per image
   const int vpr = d >> 3;
   const int64_t total = (int64_t)N * (G2 + 1) * vpr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int v = (int)(i % vpr);
     const int64_t row = i / vpr;
     const int tkn = (int)(row % (G2 + 1));
-    const int n = (int)(row / (G2 + 1));
     float a[8], b[8];
     if (tkn == 0) unpack8<DT>(((const uint4*)cls)[v], a);
-    else unpack8<DT>(((const uint4*)(patch + ((int64_t)n * G2 + tkn - 1) * d))[v], a);
+    else unpack8<DT>(((const uint4*)(patch + row * d))[v], a);
     unpack8<DT>(((const uint4*)(pos + (int64_t)tkn * d))[v], b);
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] += b[k];
     ((uint4*)(x + row * d))[v] = pack8<DT>(a);
+  }
+}
+
+// dst[r, c] (=|+=) src[r, c] for a [rows, cols] block of two row-major 16-bit matrices with their own row strides (pad /
+// un-pad of the patch-embedding weight and its gradient: widths that are not a multiple of 8 elements)
+template <int DT>
+__global__ __launch_bounds__(256) void copy2d_k(const uint16_t* __restrict__ src, int64_t lds_, uint16_t* __restrict__ dst, int64_t ldd,
+                                                int rows, int cols, int accumulate) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const uint16_t s = src[r * lds_ + c];
+    uint16_t* d = dst + r * ldd + c;
+    *d = accumulate ? (uint16_t)st16<DT>(ld16<DT>(*d) + ld16<DT>(s)) : s;
   }
 }
 
@@ -314,15 +331,22 @@ extern "C" int mh_rope_qk(void* qkv, const float* cos_sin, int T, int S, int H, 
   DISPATCH16(dt, rope_qk_k, grid_for((int64_t)T * 2 * H * (D / 16)), (uint16_t*)qkv, (const float2*)cos_sin, (int64_t)T, S, H, D, inverse);
   MH_LAUNCH_CHECK();
 }
-extern "C" int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img, int ps, int Kpad, int dt, void* stream) {
+extern "C" int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int N, int img, int ps, int Kpad, int rows_per_img,
+                                 int row0, int dt, void* stream) {
   if (!pixels || !cols || N <= 0 || img % ps != 0 || Kpad < 3 * ps * ps) return MH_ERR_ARG;
   const int G = img / ps;
-  DISPATCH16(dt, im2col_k, grid_for((int64_t)N * G * G * Kpad), pixels, pix_dt, (uint16_t*)cols, N, img, ps, Kpad);
+  if (row0 < 0 || rows_per_img < row0 + G * G) return MH_ERR_ARG;
+  DISPATCH16(dt, im2col_k, grid_for((int64_t)N * rows_per_img * Kpad), pixels, pix_dt, (uint16_t*)cols, N, img, ps, Kpad, rows_per_img, row0);
   MH_LAUNCH_CHECK();
 }
 extern "C" int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x, int N, int G2, int d, int dt, void* stream) {
   if (!patch || !cls || !pos || !x || N <= 0 || (d & 7)) return MH_ERR_ARG;
   DISPATCH16(dt, vit_assemble_k, grid_for((int64_t)N * (G2 + 1) * (d >> 3)), (const uint16_t*)patch, (const uint16_t*)cls, (const uint16_t*)pos, (uint16_t*)x, N, G2, d);
+  MH_LAUNCH_CHECK();
+}
+extern "C" int mh_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int accumulate, int dt, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return MH_ERR_ARG;
+  DISPATCH16(dt, copy2d_k, grid_for((int64_t)rows * cols), (const uint16_t*)src, lds, (uint16_t*)dst, ldd, rows, cols, accumulate);
   MH_LAUNCH_CHECK();
 }
 extern "C" int mh_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

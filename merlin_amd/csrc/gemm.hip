@@ -404,6 +404,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   bool big = t256 >= 192;
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
+#ifdef MH_DEV_ARMS  // alternative tilings kept for A/B timing (tools/dev_arms/): compiled only into the dev library
   if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arm: MFMA 32x32x16 fragments
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
@@ -429,6 +430,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
       return launch_gemm_nt_w8(g, dt, as_stream(stream));
     }
   }
+#endif
   if (rope.sw_mode == 1) {  // a tile = 128 gate + 128 up columns
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (rope.sw_ff + 127) / 128;

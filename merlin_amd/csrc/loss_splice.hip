@@ -215,6 +215,39 @@ __global__ __launch_bounds__(256) void mask_lens_k(const uint8_t* __restrict__ m
   if (threadIdx.x == 0) lens[b] = max(max(best[0], best[1]), max(best[2], best[3]));
 }
 
+// Input validation on the device (one block per sample, no host sync): the reference raises on these through torch itself
+// (embedding index out of range, CE target out of bounds) and honours arbitrary masks; this path supports right-padded masks
+// only (lens), so anything else must fail loudly instead of being read as a dense prefix.
+//   err[4] = 1: an input id outside [0, V)      (err[5] = flat position)
+//   err[6] = 1: a label that is neither -100 nor in [0, V)   (err[7] = flat position)
+//   err[8] = 1: attention_mask of sample err[9] is not a right-padded prefix (popcount != 1 + last set position)
+__global__ __launch_bounds__(256) void check_inputs_k(const int64_t* __restrict__ ids, const int64_t* __restrict__ labels,
+                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ lens,
+                                                      int32_t* __restrict__ err, int S, int V) {
+  __shared__ int cnt[4];
+  const int b = blockIdx.x;
+  int c = 0;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const int64_t t = (int64_t)b * S + s;
+    if (ids) {
+      const int64_t id = ids[t];
+      if (id < 0 || id >= V) { if (atomicExch(&err[4], 1) == 0) err[5] = (int)t; }
+    }
+    if (labels) {
+      const int64_t l = labels[t];
+      if (l != -100 && (l < 0 || l >= V)) { if (atomicExch(&err[6], 1) == 0) err[7] = (int)t; }
+    }
+    if (mask && mask[t]) ++c;
+  }
+  if (mask) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt[0] + cnt[1] + cnt[2] + cnt[3] != lens[b]) { if (atomicExch(&err[8], 1) == 0) err[9] = b; }
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -273,6 +306,13 @@ extern "C" int mh_splice_index(const int64_t* ids, const int32_t* img_offset, in
 extern "C" int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream) {
   if (!mask_u8 || !lens || B <= 0 || S <= 0) return MH_ERR_ARG;
   hipLaunchKernelGGL(mask_lens_k, dim3(B), dim3(256), 0, as_stream(stream), (const uint8_t*)mask_u8, lens, S);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_check_inputs(const int64_t* ids, const int64_t* labels, const void* mask_u8, const int32_t* lens, int32_t* err,
+                               int B, int S, int V, void* stream) {
+  if (!err || B <= 0 || S <= 0 || V <= 0 || (mask_u8 && !lens)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(check_inputs_k, dim3(B), dim3(256), 0, as_stream(stream), ids, labels, (const uint8_t*)mask_u8, lens, err, S, V);
   MH_LAUNCH_CHECK();
 }
 

@@ -6,38 +6,84 @@ Buckets are the engine's natural units (one decoder / encoder layer = one contig
 gradient arena, ~405 MB bf16 for a Llama-7B layer): `engine.on_grads_ready(names)` fires as soon as a
 layer's weight gradients are final; the bucket's all-reduce is enqueued on a dedicated communication
 stream that waits on an event recorded on the compute stream, so it runs under the remaining backward
-GEMMs.  xGMI is point-to-point (7 links/GPU): few, large collectives per step (35 for the 7B model)
-rather than many small ones.  The mean over ranks (mean of per-rank mean losses, as the reference's DP
-does) is folded into the optimizer's grad scale (1/world_size)."""
+GEMMs.  xGMI is point-to-point (7 links/GPU): few, large collectives per step (35 + 23 CLIP layers for
+the 7B model) rather than many small ones.  The mean over ranks (mean of per-rank mean losses, as the
+reference's DP does) is folded into the optimizer's grad scale (1/world_size).
+
+The engine fires EVERY trainable bucket on EVERY backward in one fixed order (buckets a rank's batch does
+not touch - a text-only batch has no image gradients - are zero-filled and still reported), so all ranks
+issue the same sequence of collectives whatever their data: the reference gets the same guarantee from
+its `0 * projector(dummy_feature)` trick (base_mmgpt.py:109-113).
+
+Gradient accumulation (pretrain.sh:18 trains with --gradient_accumulation_steps 8; SURVEY §8e "reduce only
+on the k-th micro-step"): micro-steps run under `no_sync()` and only accumulate locally; the last one
+all-reduces the accumulated sum.  A backward that would accumulate onto gradients that were already
+all-reduced raises instead of silently counting the first micro-batch world^(k-1) times."""
 from __future__ import annotations
+
+import contextlib
 
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, engine, process_group=None, bucket_bytes_min=0):
+    def __init__(self, engine, process_group=None, force=False):
+        """force=True runs the collectives even when world_size == 1 (exercises the stream / event path on one GPU)."""
         self.engine = engine
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.comm_stream = None
         self.pending = []
         self.n_collectives = 0
         self.bytes = 0
+        self.order = []  # bucket (offset, numel) sequence of the last synced backward (tests compare it across ranks)
+        self._sync = True
+        self._reduced = False  # the gradient arena holds all-reduced sums (until the next fresh backward)
         engine.on_grads_ready = self._on_ready
+        engine.on_backward_begin = self._on_begin
+
+    # ---- gradient accumulation ------------------------------------------------------------------
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backwards inside this context accumulate locally; no collective is issued (DDP.no_sync semantics)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def accumulate(self, micro_step: int, accumulation_steps: int):
+        """Context for micro-step `micro_step` (0-based) of an accumulation window: syncs only on the last one."""
+        if (micro_step + 1) % accumulation_steps == 0:
+            return contextlib.nullcontext()
+        return self.no_sync()
+
+    # ---- engine callbacks -----------------------------------------------------------------------
+    def _on_begin(self, fresh: bool):
+        if fresh:
+            self._reduced = False
+        elif self._reduced and self.active:
+            raise RuntimeError("merlin_amd.dp: this backward accumulates onto gradients that were already all-reduced; run all "
+                               "but the last micro-step of an accumulation window under GradSync.no_sync() (or zero_grad first)")
+        if self._sync:
+            self.order = []
 
     def _on_ready(self, names):
-        if self.world == 1:
+        if not self.active or not self._sync:
             return
         A = self.engine.arena
         if names is None:  # end of backward: join the communication stream
             self.finish()
+            self._reduced = True
             return
         names = [n for n in names if A.params[n].requires_grad]
         if not names:
             return
         off, num = A.range_of(names)
         buf = A.gflat[off: off + num]
+        self.order.append((off, num))
         if buf.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=buf.device)

@@ -49,9 +49,12 @@ class HipEngine:
         self._arena_sig = None
         self.rope = None
         self.save_activations = False
-        self.on_grads_ready = None  # callable(list_of_param_names) | None
+        self.on_grads_ready = None  # callable(list_of_param_names) | None: a bucket's gradients are final (dp.GradSync)
+        self.on_backward_begin = None  # callable(fresh: bool) | None
         self.strict_checks = True
         self._err = None
+        self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
+        self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
 
     # ------------------------------------------------------------------------------------------
     # parameter arena
@@ -141,6 +144,19 @@ class HipEngine:
                 self.vit.append(W)
         self._bind = True
         self.rope = None
+        self.weights_changed()
+
+    def weights_changed(self):
+        """Parameter values changed (optimizer step, checkpoint load, init, repack): drop every derived copy."""
+        self.weight_version += 1
+        self._derived = {}
+        self._fp8 = self._fp8_fwd = None
+
+    def _derive(self, key, make):
+        hit = self._derived.get(key)
+        if hit is None or hit[0] != self.weight_version:
+            hit = self._derived[key] = (self.weight_version, make())
+        return hit[1]
 
     def _trainable(self, name):
         return self.arena.params[name].requires_grad
@@ -175,6 +191,15 @@ class HipEngine:
     def _ready(self, names):
         if self.on_grads_ready is not None:
             self.on_grads_ready(names)
+
+    def _untouched(self, names, fresh):
+        """A trainable bucket this backward does not reach: zero it on the first micro-step (the arena may hold the previous
+        step's values), leave accumulated values alone otherwise, and report it like any other bucket."""
+        if fresh:
+            for n in names:
+                if self.arena.params[n].requires_grad:
+                    self.arena.gview(n).zero_()
+        self._ready(names)
 
     # ------------------------------------------------------------------------------------------
     # vision tower
@@ -244,20 +269,30 @@ class HipEngine:
         A = self.arena
         dt = A.flat.dtype
         dev = A.flat.device
-        pix = torch.cat([im for im in images], dim=0).to(device=dev)
-        if pix.dtype not in (torch.float32, dt):
-            pix = pix.float()
-        pix = pix.contiguous()
-        N = pix.shape[0]
         G = vc.image_size // vc.patch_size
         G2 = G * G
         S = G2 + 1
         vd = vc.hidden_size
         K = 3 * vc.patch_size * vc.patch_size
         Kpad = _ru(K, 64)
-        cols = O.im2col_patches(pix, vc.patch_size, Kpad, dt)
-        wpad = torch.zeros(vd, Kpad, dtype=dt, device=dev)
-        wpad[:, :K].copy_(A.view(VT + "embeddings.patch_embedding.weight", shape=(vd, K)))  # layout plumbing (zero-pad K)
+        N = sum(int(im.shape[0]) for im in images)
+        # patch rows are gathered straight into the tower's token-major layout [N, 1 + G2, Kpad] (zero CLS slot per image), one
+        # launch per image tensor of the batch: no torch.cat of the pixels, and the weight gradient is one GEMM over all rows
+        cols = torch.empty(N * S, Kpad, dtype=dt, device=dev)
+        r = 0
+        for im in images:
+            im = im.to(device=dev)
+            if im.dtype not in (torch.float32, dt):
+                im = im.float()
+            n = int(im.shape[0])
+            O.im2col_patches(im.contiguous(), vc.patch_size, Kpad, dt, rows_per_img=S, row0=1, out=cols[r * S:(r + n) * S])
+            r += n
+
+        def _pad_patch_weight():  # K = 588 -> 640 (zero tail), once per weight version
+            wp = torch.zeros(vd, Kpad, dtype=dt, device=dev)
+            return O.copy2d(A.view(VT + "embeddings.patch_embedding.weight", shape=(vd, K)), wp)
+
+        wpad = self._derive("patch_wpad", _pad_patch_weight)
         patch = O.gemm_nt(cols, wpad)
         x0 = O.vit_assemble(patch, A.view(VT + "embeddings.class_embedding"), A.view(VT + "embeddings.position_embedding.weight", shape=(S, vd)), N, G2)
         x = O.layernorm_fwd(x0, A.view(VT + "pre_layrnorm.weight"), A.view(VT + "pre_layrnorm.bias"), vc.layer_norm_eps)
@@ -294,18 +329,13 @@ class HipEngine:
         # position embedding / class embedding grads: sums over images (column sums of [N, S*vd] and of the CLS rows)
         O.colsum(dx0.view(N, S * vd), A.gview(VT + "embeddings.position_embedding.weight").view(S * vd), accumulate=acc)
         O.colsum(d3[:, 0, :], A.gview(VT + "embeddings.class_embedding"), accumulate=acc)
-        # patch embedding weight grad: dW[vd, K] = dpatch^T @ cols
+        # patch embedding weight grad: dW[vd, Kpad] = dx0^T @ cols over ALL token rows (the CLS rows of cols are zero): one
+        # K-strided MFMA GEMM on the operands as they lie in memory, then the K-padding is dropped by a strided copy
         K = 3 * vc.patch_size * vc.patch_size
         Kpad = ctx["vit_Kpad"]
-        dpatch = d3[:, 1:, :].contiguous().view(N * G2, vd)  # layout plumbing: drop the CLS rows
-        gw = torch.zeros(vd, Kpad, dtype=dx0.dtype, device=dx0.device)
-        Tp = _ru(N * G2, 64)
-        O.gemm_nt(O.transpose16(dpatch, r_pad=Tp), O.transpose16(ctx["vit_cols"], r_pad=Tp), out=gw)
-        g = A.gview(VT + "embeddings.patch_embedding.weight").view(vd, K)
-        if acc:
-            O.add(g, gw[:, :K].contiguous(), out=g)  # .contiguous(): layout plumbing (un-pad K)
-        else:
-            g.copy_(gw[:, :K])
+        gw = torch.empty(vd, Kpad, dtype=dx0.dtype, device=dx0.device)
+        O.wgrad_tn(dx0, ctx["vit_cols"], gw, accum=False)
+        O.copy2d(gw[:, :K], A.gview(VT + "embeddings.patch_embedding.weight").view(vd, K), accumulate=acc)
         self._ready([n for n in A.names if n.startswith(VT + "embeddings.") or n.startswith(VT + "pre_layrnorm")])
 
     # ------------------------------------------------------------------------------------------
@@ -465,22 +495,49 @@ class HipEngine:
             raise ValueError(f"The number of image start tokens and image end tokens should be the same (sample {e[2]}, difference {e[3]}).")
         if e[1]:
             raise ValueError(f"The image end token should follow the image start token (sample {e[2]}, <im_start> at {e[3]}).")
+        if e[4]:
+            raise IndexError(f"index out of range in self: input_ids holds an id outside [0, vocab_size) at flat position {e[5]}")
+        if e[6]:
+            raise IndexError(f"Target out of bounds: labels holds a value that is neither -100 nor in [0, vocab_size) at flat position {e[7]}")
+        if e[8]:
+            raise ValueError(f"attention_mask of sample {e[9]} is not right-padded (ones followed by zeros): the HIP path implements the "
+                             "key-padding branch of the flash-attention patch for right-padded batches (collator.py:29-34) only")
 
-    def splice_index(self, input_ids, images, P, rows_per_img, row0):
+    def _splice_geometry(self):
+        """(rows per image in the projector output, first patch row, P = image tokens per image) from the configs alone, so the
+        index / validation kernels can run BEFORE the tower (their flags are read back while the GPU is busy with it)."""
+        inner = self.model.get_model()
+        tower, proj = inner.vision_tower, inner.projector
+        vc = tower.config
+        G = vc.image_size // vc.patch_size
+        if hasattr(proj, "conv_stride"):
+            Go = (G + 2 - 3) // proj.conv_stride + 1
+            return Go * Go, 0, Go * Go
+        S = G * G + 1
+        cls_keep = tower.select_feature == "cls_patch"
+        return S, (0 if cls_keep else 1), (S if cls_keep else S - 1)
+
+    def validate_and_index(self, input_ids, labels, mask, lens, images, use_images):
+        """One pass of device-side input checks (+ the splice row table when the batch carries images); returns src | None."""
         m = self.model
-        dev = input_ids.device
-        counts = [int(im.shape[0]) for im in images]
-        off = [0]
-        for c in counts:
-            off.append(off[-1] + c)
-        B = input_ids.shape[0]
-        off = (off + [off[-1]] * (B + 1))[: B + 1]  # fewer image entries than samples: zip() semantics
-        img_off = torch.tensor(off, dtype=torch.int32).to(dev, non_blocking=True)
-        err_dev = torch.zeros(4, dtype=torch.int32, device=dev)
-        src = O.splice_index(input_ids, img_off, P, m.im_patch_token, m.im_start_token, m.im_end_token, err_dev,
-                             rows_per_img=rows_per_img, row0=row0)
+        dev = self.arena.flat.device
+        err_dev = torch.zeros(10, dtype=torch.int32, device=dev)
+        src = None
+        if use_images:
+            rpi, row0, P = self._splice_geometry()
+            counts = [int(im.shape[0]) for im in images]
+            off = [0]
+            for c in counts:
+                off.append(off[-1] + c)
+            B = input_ids.shape[0]
+            off = (off + [off[-1]] * (B + 1))[: B + 1]  # fewer image entries than samples: zip() semantics
+            img_off = torch.tensor(off, dtype=torch.int32).to(dev, non_blocking=True)
+            src = O.splice_index(input_ids, img_off, P, m.im_patch_token, m.im_start_token, m.im_end_token, err_dev,
+                                 rows_per_img=rpi, row0=row0)
         if self.strict_checks:
-            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            if input_ids is not None or labels is not None or mask is not None:
+                O.check_inputs(input_ids, labels, mask, lens, err_dev, m.config.vocab_size)
+            host = torch.empty(10, dtype=torch.int32, pin_memory=True)
             host.copy_(err_dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -515,22 +572,23 @@ class HipEngine:
                 am = am != 0
             lens = O.mask_lens(am.contiguous())
         ctx["lens"] = lens
+        if labels is not None:
+            labels = labels.to(dev).contiguous()
         # ---- multimodal splice (base_mmgpt.py:82-165) ----
-        src = None
         feats = None
         use_images = tower is not None and images is not None and input_ids is not None and S != 1
+        src = self.validate_and_index(input_ids, labels, am.contiguous() if attention_mask is not None else None, lens, images, use_images)
         if use_images:
             xt, N, Sv = self.tower(images, ctx)
             feats, rpi, row0, P = self.projector(xt, N, Sv, ctx)
-            src = self.splice_index(input_ids, images, P, rpi, row0)
+            assert (rpi, row0, P) == self._splice_geometry()
             ctx.update(src=src, n_feat_rows=feats.shape[0])
+        self._check_errors()  # the flags were produced before the tower was enqueued: no wait for compute
         if inputs_embeds is not None:
             x = inputs_embeds.to(device=dev, dtype=dt).reshape(T, d).contiguous()
         else:
             x = O.embed_splice_fwd(input_ids.view(-1), src.view(-1) if src is not None else None,
                                    A.view("model.embed_tokens.weight", shape=(cfg.vocab_size, d)), feats)
-        if use_images:
-            self._check_errors()
         ctx["ids"] = input_ids
         del feats
         # ---- decoder ----
@@ -560,12 +618,11 @@ class HipEngine:
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
         if last_only:  # prefill of generate(): only each sequence's last valid position feeds the sampler
             last = (lens.to(torch.int64) - 1) if lens is not None else torch.full((B,), S - 1, dtype=torch.int64, device=dev)
-            rows = hn.index_select(0, torch.arange(B, device=dev) * S + last.clamp_min(0))
+            rows = O.gather_rows(hn, torch.arange(B, device=dev) * S + last.clamp_min(0))
             return None, O.gemv(rows, wlm, out_f32=True, n=V), ctx
         logits = O.gemm_nt(hn, wlm, out_f32=True)  # [T, Vpad] fp32
         loss = None
         if labels is not None:
-            labels = labels.to(dev).contiguous()
             row_loss, lse, out = O.ce_fwd(logits, labels, V)
             loss = out[2]
             ctx.update(labels=labels, ce_lse=lse, ce_out=out)
@@ -584,8 +641,13 @@ class HipEngine:
         Tpad = _ru(T, 64)
         dt = A.flat.dtype
         fresh = A.ensure_grads()
+        if self.on_backward_begin is not None:
+            self.on_backward_begin(fresh)
         acc = not fresh
         lens = ctx["lens"]
+        # Every trainable bucket is reported through _ready() on EVERY backward, in one fixed order (head, decoder layers
+        # L-1..0, embedding, projector, tower layers, tower embeddings), whatever this rank's batch contained: the
+        # data-parallel all-reduce sequence is then identical on all ranks (merlin_amd/dp.py).
         # ---- head ----
         dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
         ctx["logits"] = None
@@ -615,15 +677,23 @@ class HipEngine:
         src = ctx.get("src")
         ids = ctx["ids"]
         inner = m.get_model()
-        emb_train = ids is not None and self._trainable("model.embed_tokens.weight")
-        need_feats = src is not None and (ctx["train_tower"] or any(p.requires_grad for p in inner.projector.parameters()))
+        tower = getattr(inner, "vision_tower", None)
+        proj = getattr(inner, "projector", None)
+        wname, bname = "model.projector.projector.weight", "model.projector.projector.bias"
+        emb_train = self._trainable("model.embed_tokens.weight")
+        proj_train = proj is not None and any(p.requires_grad for p in proj.parameters())
+        tower_train = tower is not None and not tower.freeze_vision_tower and any(p.requires_grad for p in tower.parameters())
+        need_feats = src is not None and (ctx["train_tower"] or proj_train)
         dfeats = torch.zeros(ctx["n_feat_rows"], d, dtype=dt, device=dx.device) if need_feats else None
-        dembed32 = torch.zeros(V, d, dtype=torch.float32, device=dx.device) if emb_train else None
+        dembed32 = torch.zeros(V, d, dtype=torch.float32, device=dx.device) if (emb_train and ids is not None) else None
         if ids is not None and (need_feats or emb_train):
             O.embed_splice_bwd(ids.view(-1), src.view(-1) if src is not None else None, dx, dfeats, dembed32)
         if emb_train:
             g = A.gview("model.embed_tokens.weight")
-            if acc:
+            if ids is None:  # inputs_embeds path: no token rows were looked up, the embedding gradient of this pass is zero
+                if fresh:
+                    g.zero_()
+            elif acc:
                 tmp = torch.empty_like(g)
                 O.convert(dembed32, tmp)
                 O.add(g, tmp, out=g)
@@ -635,20 +705,26 @@ class HipEngine:
             dxt = self.projector_bwd(ctx, dfeats, fresh)
             if ctx["train_tower"]:
                 self.tower_bwd(ctx, dxt, fresh)
-        # parameters this backward never touches (e.g. CLIP layers past select_layer, post_layernorm)
-        if fresh:
-            touched_prefixes = None
-            tower = getattr(inner, "vision_tower", None)
-            if tower is not None:
-                L = tower.layers_used
-                for n in A.names:
-                    if not A.params[n].requires_grad:
-                        continue
-                    dead = n.startswith(VT + "post_layernorm") or any(n.startswith(VT + f"encoder.layers.{i}.") for i in range(L, tower.config.num_hidden_layers))
-                    untrained_tower = n.startswith(VT) and not ctx["train_tower"]
-                    unused_mm = (n.startswith(VT) or n.startswith("model.projector.")) and src is None
-                    if dead or untrained_tower or unused_mm:
-                        A.gview(n).zero_()
+        elif src is None:
+            # a batch without image tokens (text-only step, decode-shaped input): image-side gradients of this pass are zero.
+            # The reference keeps those parameters in the graph with `0 * projector(dummy_feature)` (base_mmgpt.py:109-113);
+            # here their buckets are zero-filled (first micro-step only) and still reported, in the usual order.
+            if proj_train:
+                self._untouched([wname, bname], fresh)
+            if tower_train:
+                for i in reversed(range(tower.layers_used)):
+                    self._untouched(self.vit[i].names, fresh)
+                self._untouched([n for n in A.names if n.startswith(VT + "embeddings.") or n.startswith(VT + "pre_layrnorm")], fresh)
+        # trainable parameters no backward ever reaches (CLIP layers past select_layer, post_layernorm; a tower whose
+        # freeze flag is set while its tensors still require grad): zero, never reported (identically on every rank)
+        if fresh and tower is not None:
+            L = tower.layers_used
+            for n in A.names:
+                if not n.startswith(VT) or not A.params[n].requires_grad:
+                    continue
+                dead = n.startswith(VT + "post_layernorm") or any(n.startswith(VT + f"encoder.layers.{i}.") for i in range(L, tower.config.num_hidden_layers))
+                if dead or not tower_train:
+                    A.gview(n).zero_()
         self._ready(None)  # end of backward
 
     # ------------------------------------------------------------------------------------------
@@ -704,7 +780,7 @@ class HipEngine:
         d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
         eps = cfg.rms_norm_eps
         emb = A.view("model.embed_tokens.weight", shape=(V, d))
-        x = emb.index_select(0, tokens.to(A.flat.device).view(-1))
+        x = O.gather_rows(emb, tokens.to(A.flat.device).view(-1))
         pos = cache.lens
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
@@ -730,7 +806,7 @@ class HipEngine:
         d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
         eps = cfg.rms_norm_eps
         emb = A.view("model.embed_tokens.weight", shape=(V, d))
-        x = emb.index_select(0, tokens.to(A.flat.device).view(-1))
+        x = O.gather_rows(emb, tokens.to(A.flat.device).view(-1))
         pos = cache.lens
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
@@ -780,11 +856,25 @@ class HipEngine:
         return torch.split(feats, [im.shape[0] for im in images], dim=0)
 
     def projector_forward_public(self, features):
+        """mlp_projector.py:19-23 / conv_projector.py:23-39 as a standalone call: list of [n_i, P, C] -> list of [n_i, P', d]."""
         self.ensure_arena()
         A = self.arena
+        proj = self.model.get_model().projector
+        wname, bname = "model.projector.projector.weight", "model.projector.projector.bias"
         out = []
         for f in features:
+            if hasattr(proj, "conv_stride"):
+                if f.dim() == 1:  # conv_projector.py:27-28: the 1-D dummy feature is tiled to 256 tokens
+                    f = f.view(1, 1, -1).repeat(1, 256, 1)
+                n, P, C = f.shape
+                G = int(math.sqrt(P))
+                x = f.to(A.flat.dtype).reshape(n * P, C).contiguous()
+                cols = O.conv3x3_cols(x, n, G, C, proj.conv_stride, P, 0)
+                w = A.view(wname, shape=(A.params[wname].shape[0], C * 9))
+                y = O.gemm_nt(cols, w, bias=A.view(bname))
+                out.append(y.view(n, -1, y.shape[-1]))
+                continue
             f2 = f.to(A.flat.dtype).reshape(-1, f.shape[-1]).contiguous()
-            y = O.gemm_nt(f2, A.view("model.projector.projector.weight"), bias=A.view("model.projector.projector.bias"))
+            y = O.gemm_nt(f2, A.view(wname), bias=A.view(bname))
             out.append(y.view(*f.shape[:-1], -1))
         return out

@@ -90,6 +90,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
         self.vocab_size = config.vocab_size
         self.lm_head = M.Linear(config.hidden_size, config.vocab_size, bias=False)
         self.engine = HipEngine(self)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.engine.weights_changed())
         self._anchor = None
         self.use_im_start_end = True
         self.use_beam_search = False
@@ -316,6 +317,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
                     p.data.copy_(tmp)
             else:
                 p.data.copy_(torch.from_numpy(W.generate(name, tuple(p.shape), seed)).to(p.dtype))
+        self.engine.weights_changed()
         return self
 
 

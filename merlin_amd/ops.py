@@ -440,30 +440,29 @@ def rope_qk_(qkv, table, S, H, D, inverse=False):
     return qkv
 
 
-def attn_prep_v(v, B, S, H, D, out=None):
-    """v: [B*S, H*D] view (row stride ldv) -> vt [B, H, D, S_pad] in the kernels' key order."""
-    S_pad = round_up(S, 64)
-    out = torch.empty(B, H, D, S_pad, dtype=v.dtype, device=v.device) if out is None else out
-    L.check(L.lib().mh_attn_prep_v(p(v), i64(v.stride(0)), p(out), i32(B), i32(S), i32(H), i32(D), i32(dt_of(v)), _stream()), "mh_attn_prep_v")
-    return out
-
-
-def attn_fwd(q, k, vt, B, S, H, D, causal, seqlens=None, out=None, lse=None):
-    """q, k: [B*S, H*D] views (row strides ldq/ldk); vt from attn_prep_v.  Returns (o [B*S, H*D], lse [B,H,S_pad])."""
-    out = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if out is None else out
-    lse = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device) if lse is None else lse
-    L.check(L.lib().mh_attn_fwd(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(vt), p(out), i64(out.stride(0)), p(lse),
-                                p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), i32(dt_of(q)), _stream()), "mh_attn_fwd")
-    return out, lse
-
-
 def attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=None, out=None, lse=None):
     """q, k, v: [B*S, H*D] views (own row strides).  Returns (o [B*S, H*D], lse [B,H,S_pad]).  No V re-layout pass."""
     out = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if out is None else out
-    lse = torch.zeros(B, H, round_up(S, 64), dtype=torch.float32, device=q.device) if lse is None else lse
+    if lse is None:  # the kernel writes rows < S; the pad rows of a ragged S_pad must read as zeros in the backward
+        lse = (torch.empty if S % 64 == 0 else torch.zeros)(B, H, round_up(S, 64), dtype=torch.float32, device=q.device)
     L.check(L.lib().mh_attn_fwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(out), i64(out.stride(0)),
                                  p(lse), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), i32(dt_of(q)), _stream()), "mh_attn_fwd2")
     return out, lse
+
+
+_delta_cache = {}
+
+
+def _delta_ws(B, H, S_pad, device):
+    """[2, B, H, S_pad] fp32 scratch of the attention backward, reused across calls (same stream => ordered).  Zeroed once:
+    the kernels only ever write rows < S, so the pad rows stay zero."""
+    key = (device, B, H, S_pad)
+    ws = _delta_cache.get(key)
+    if ws is None:
+        if len(_delta_cache) > 8:
+            _delta_cache.clear()
+        ws = _delta_cache[key] = torch.zeros(2, B, H, S_pad, dtype=torch.float32, device=device)
+    return ws
 
 
 def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None, rope=None):
@@ -472,7 +471,7 @@ def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk
     dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
     dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
-    delta = torch.zeros(2, B, H, round_up(S, 64), dtype=torch.float32, device=q.device)  # [delta | lse*log2e]
+    delta = _delta_ws(B, H, round_up(S, 64), q.device)  # [delta | lse*log2e]
     L.check(L.lib().mh_attn_bwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
                                  p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
                                  p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), p(rope),
@@ -480,26 +479,33 @@ def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk
     return dq, dk, dv
 
 
-def attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None):
-    dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
-    dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
-    dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
-    delta = torch.zeros(2, B, H, round_up(S, 64), dtype=torch.float32, device=q.device)  # [delta | lse*log2e]
-    ws = torch.empty(int(L.lib().mh_attn_bwd_ws_elems(i32(B), i32(S), i32(H), i32(D))), dtype=q.dtype, device=q.device)
-    L.check(L.lib().mh_attn_bwd(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
-                                p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
-                                p(dv), i64(dv.stride(0)), p(ws), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)),
-                                i32(dt_of(q)), _stream()), "mh_attn_bwd")
-    return dq, dk, dv
-
-
-def im2col_patches(pixels, ps, kpad, dtype):
+def im2col_patches(pixels, ps, kpad, dtype, rows_per_img=None, row0=0, out=None):
+    """pixels [N,3,H,H] -> cols [N*rows_per_img, kpad]; patch p of image n at row n*rows_per_img + row0 + p, rows below
+    row0 (the CLS slot) zero.  `out`: write into a caller-provided row range (one launch per image tensor of a batch)."""
     N, Cc, Himg, Wimg = pixels.shape
     assert Cc == 3 and Himg == Wimg and pixels.is_contiguous()
     G = Himg // ps
-    cols = torch.empty(N * G * G, kpad, dtype=dtype, device=pixels.device)
-    L.check(L.lib().mh_im2col_patches(p(pixels), i32(dt_of(pixels)), p(cols), i32(N), i32(Himg), i32(ps), i32(kpad), i32(dt_of(dtype)), _stream()), "mh_im2col_patches")
+    rpi = G * G + row0 if rows_per_img is None else rows_per_img
+    cols = torch.empty(N * rpi, kpad, dtype=dtype, device=pixels.device) if out is None else out
+    assert cols.shape == (N * rpi, kpad) and cols.is_contiguous()
+    L.check(L.lib().mh_im2col_patches(p(pixels), i32(dt_of(pixels)), p(cols), i32(N), i32(Himg), i32(ps), i32(kpad), i32(rpi), i32(row0),
+                                      i32(dt_of(dtype)), _stream()), "mh_im2col_patches")
     return cols
+
+
+def copy2d(src, dst, accumulate=False):
+    """dst[r, c] (=|+=) src[r, c] over src's [rows, cols] block; both row-major 16-bit with their own row strides."""
+    rows, cols = src.shape
+    assert dst.shape[0] >= rows and dst.shape[1] >= cols and src.dtype == dst.dtype
+    L.check(L.lib().mh_copy2d(p(src), i64(_rowmajor(src)), p(dst), i64(_rowmajor(dst)), i32(rows), i32(cols), i32(int(accumulate)),
+                              i32(dt_of(src)), _stream()), "mh_copy2d")
+    return dst
+
+
+def gather_rows(table, idx, out=None):
+    """out[i, :] = table[idx[i], :] (idx int64 on the device): the embedding-gather kernel without a splice table."""
+    assert idx.dtype == torch.int64 and table.is_contiguous()
+    return embed_splice_fwd(idx.contiguous().view(-1), None, table, None, out=out)
 
 
 def vit_assemble(patch, cls, pos, N, G2):
@@ -536,6 +542,14 @@ def mask_lens(mask):
     lens = torch.empty(B, dtype=torch.int32, device=mask.device)
     L.check(L.lib().mh_mask_lens(p(mask), p(lens), i32(B), i32(S), _stream()), "mh_mask_lens")
     return lens
+
+
+def check_inputs(ids, labels, mask, lens, err, V):
+    """Device-side validation (ids / labels in range, right-padded mask); flags land in err[4:10] (int32[10])."""
+    ref = ids if ids is not None else (labels if labels is not None else mask)
+    B, S = ref.shape
+    assert err.numel() >= 10 and err.dtype == torch.int32
+    L.check(L.lib().mh_check_inputs(p(ids), p(labels), p(mask), p(lens), p(err), i32(B), i32(S), i32(V), _stream()), "mh_check_inputs")
 
 
 def embed_splice_fwd(ids, src, embed, feats, out=None):
@@ -594,5 +608,6 @@ def sumsq(g, out):
 
 
 def gemm_force_kernel(which: int):
-    """0 = auto, 128 / 256 = force that tile size (tests, A/B benchmarks)."""
+    """0 = auto, 128 / 256 = force that tile size (tests, A/B benchmarks).  Other codes select the development arms and
+    exist only in the dev library (tools/dev_arms/)."""
     L.lib().mh_gemm_force_kernel(i32(which))

@@ -32,35 +32,17 @@ def llm_lr_scale(name: str) -> float:
     return 1
 
 
-def param_groups(named_parameters, lr, weight_decay, lr_scale_fn=None):
-    """The reference's grouping (llrd_utils.py:26-79): trainable parameters split by (decayed or not: biases and 1-D
-    tensors are not) x (lr multiplier), in the reference's group order.  Returns a list of dicts
-    {"names": [...], "weight_decay": wd, "lr": lr * mult}."""
-    wd_plain, wd_scaled, nowd_plain, nowd_scaled = [], {}, [], {}
+def per_param_hparams(named_parameters, lr, weight_decay, lr_scale_fn=None):
+    """{name: (lr, weight_decay)} for the trainable parameters: the two rules of the reference's optimizer construction
+    (trainer.py:45-74 / llrd_utils.py:26-79) - biases and 1-D tensors are not decayed; lr is scaled per layer by lr_scale_fn.
+    (The reference materialises this as torch param groups; the fused optimizer keeps it per arena range instead.)"""
+    out = {}
     for name, prm in named_parameters:
         if not prm.requires_grad:
             continue
-        no_wd = name.endswith(".bias") or prm.dim() == 1
-        mult = lr_scale_fn(name) if lr_scale_fn is not None else 1
-        scaled = mult != 1
-        if not no_wd and not scaled:
-            wd_plain.append(name)
-        elif not no_wd:
-            wd_scaled.setdefault(mult, []).append(name)
-        elif not scaled:
-            nowd_plain.append(name)
-        else:
-            nowd_scaled.setdefault(mult, []).append(name)
-    groups = []
-    if wd_plain:
-        groups.append({"names": wd_plain, "weight_decay": weight_decay, "lr": lr})
-    for mult, names in wd_scaled.items():
-        groups.append({"names": names, "weight_decay": weight_decay, "lr": lr * mult})
-    if nowd_plain:
-        groups.append({"names": nowd_plain, "weight_decay": 0.0, "lr": lr})
-    for mult, names in nowd_scaled.items():
-        groups.append({"names": names, "weight_decay": 0.0, "lr": lr * mult})
-    return groups
+        wd = 0.0 if (name.endswith(".bias") or prm.dim() == 1) else weight_decay
+        out[name] = (lr * (lr_scale_fn(name) if lr_scale_fn is not None else 1), wd)
+    return out
 
 
 def cosine_with_warmup(step: int, total_steps: int, warmup_ratio: float = 0.0, num_cycles: float = 0.5) -> float:
@@ -87,24 +69,26 @@ class FusedAdamW:
 
     def _build(self):
         A = self.engine.ensure_arena()
-        if self._flat_id == A.flat.data_ptr() and self._runs is not None:
+        sig = (A.flat.data_ptr(), tuple(p.requires_grad for p in A.params.values()))  # freeze / unfreeze rebuilds the runs
+        if self._flat_id == sig and self._runs is not None:
             return A
-        self.m = torch.zeros(A.total, dtype=torch.float32, device=A.flat.device)
-        self.v = torch.zeros(A.total, dtype=torch.float32, device=A.flat.device)
+        if self.m is None or self.m.numel() != A.total or self.m.device != A.flat.device:
+            self.m = torch.zeros(A.total, dtype=torch.float32, device=A.flat.device)
+            self.v = torch.zeros(A.total, dtype=torch.float32, device=A.flat.device)
+        hp = per_param_hparams(A.params.items(), 1.0, self.weight_decay, self.lr_scale_fn)  # lr as a multiplier of self.lr
         runs = []
         for n in A.names:
             p = A.params[n]
             if not p.requires_grad:
                 continue
-            wd = 0.0 if (p.dim() <= 1 or n.endswith(".bias")) else self.weight_decay
-            sc = 1.0 if self.lr_scale_fn is None else float(self.lr_scale_fn(n))
+            sc, wd = hp[n]
             off, num = A.offset[n], p.numel()
             if runs and runs[-1][2] == sc and runs[-1][3] == wd and runs[-1][0] + runs[-1][1] <= off and off - (runs[-1][0] + runs[-1][1]) < 256:
                 runs[-1][1] = off + num - runs[-1][0]  # merge (alignment gaps hold zeros and stay zero)
             else:
                 runs.append([off, num, sc, wd])
         self._runs = runs
-        self._flat_id = A.flat.data_ptr()
+        self._flat_id = sig
         return A
 
     @torch.no_grad()
@@ -130,6 +114,7 @@ class FusedAdamW:
                 O.adamw_(*args)
             else:
                 O.adamw_clip_(*args, clip)
+        self.engine.weights_changed()  # derived copies (fp8 weights, padded patch-embedding weight) are stale now
 
     def last_grad_norm(self):
         """Total gradient norm seen by the last clipped step (device scalar; what HF logs as grad_norm)."""

@@ -19,9 +19,34 @@ def _free_port():
 
 
 class _FakeEngine:
-    def __init__(self, arena):
+    """Stands in for HipEngine.backward's bucket protocol on CPU tensors: on_backward_begin(fresh), then every bucket in
+    the fixed order, then None."""
+
+    def __init__(self, arena, buckets=None):
         self.arena = arena
         self.on_grads_ready = None
+        self.on_backward_begin = None
+        self.buckets = buckets
+        self.fresh = True
+
+    def backward(self, value):
+        """local gradient of this micro-step = `value` everywhere (written when fresh, accumulated otherwise)."""
+        A = self.arena
+        if self.on_backward_begin is not None:
+            self.on_backward_begin(self.fresh)
+        for names in self.buckets:
+            for n in names:
+                g = A.gview(n)
+                if self.fresh:
+                    g.fill_(value)
+                else:
+                    g.add_(value)
+            self.on_grads_ready(names)
+        self.on_grads_ready(None)
+        self.fresh = False
+
+    def zero_grad(self):
+        self.fresh = True
 
 
 def _worker(rank, world, port, q):
@@ -65,17 +90,68 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gradsync_world2_gloo():
+def _run2(worker):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)], res
+    return sorted(res)
+
+
+def test_gradsync_world2_gloo():
+    res = _run2(_worker)
+    assert res == [(0, True), (1, True)], res
+
+
+def _accum_worker(rank, world, port, q):
+    """Gradient accumulation (pretrain.sh:18: --gradient_accumulation_steps 8; SURVEY §8e "reduce only on the k-th
+    micro-step"): k micro-steps, only the last one all-reduces; result = sum over ranks of the sum over micro-steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from merlin_amd.dp import GradSync
+        from merlin_amd.model.arena import Arena
+
+        names = [f"model.layers.{i}.{n}" for i in range(2) for n in ("a.weight", "norm.weight")] + ["lm_head.weight"]
+        A = Arena([(n, nn.Parameter(torch.zeros(130 if "norm" not in n else 7))) for n in names])
+        A.flat = torch.zeros(A.total)
+        A.gflat = torch.full((A.total,), 1234.0)  # stale values from "the previous step"
+        buckets = [["lm_head.weight"], [n for n in names if ".1." in n], [n for n in names if ".0." in n]]
+        eng = _FakeEngine(A, buckets)
+        sync = GradSync(eng)
+        ok = True
+        k = 3
+        for step in range(2):
+            eng.zero_grad()
+            before = sync.n_collectives
+            for i in range(k):
+                with sync.accumulate(i, k):
+                    eng.backward(float((rank + 1) * (i + 1) + 10 * step))
+                if i < k - 1:
+                    ok &= sync.n_collectives == before  # nothing reduced on the first k-1 micro-steps
+            want = sum(sum((r + 1) * (i + 1) + 10 * step for i in range(k)) for r in range(world))
+            ok &= sync.n_collectives == before + len(buckets)
+            ok &= all(bool((A.gview(n) == float(want)).all()) for n in names)
+            ok &= sync.order == [A.range_of(b) for b in buckets]  # the fixed bucket order (identical on every rank)
+        # accumulating onto all-reduced gradients without no_sync is an error, not silent double counting
+        try:
+            eng.backward(1.0)
+            ok = False
+        except RuntimeError as e:
+            ok &= "no_sync" in str(e)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_accumulation_reduces_only_on_last_micro_step():
+    res = _run2(_accum_worker)
+    assert res == [(0, True), (1, True)], res
 
 
 def test_arena_layout_and_fused_spans():

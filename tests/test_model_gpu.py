@@ -329,7 +329,9 @@ def test_fused_adamw_llrd_clip_schedule_vs_torch_adamw():
     master = {n: p.detach().float().clone().requires_grad_(True) for n, p in named}
     for n, p in named:
         master[n].grad = p.grad.detach().float().clone()
-    groups = OPT.param_groups(named, lr * mult, wd, OPT.vit_lr_scale)
+    from oracle import llrd_ref
+
+    groups = llrd_ref.param_groups(named, lr * mult, wd, OPT.vit_lr_scale)
     ref_opt = torch.optim.AdamW([{"params": [master[n] for n in g["names"]], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in groups],
                                 betas=(0.9, 0.95), eps=1e-8)
     total = torch.nn.utils.clip_grad_norm_([master[n] for n, _ in named], clip_at)

@@ -244,14 +244,10 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     qkv = rnd(B * S, 3 * H * D, dtype=dtype, scale=1.0)
     q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
     lens_t = torch.tensor(lens if lens else [S] * B, dtype=torch.int32, device=dev())
-    vt = ops.attn_prep_v(v, B, S, H, D)
-    o, lse = ops.attn_fwd(q, k, vt, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    o, lse = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens_t if lens else None)
     q32, k32, v32 = (t.float().reshape(B, S, H, D).clone().requires_grad_() for t in (q, k, v))
     ref = _attn_ref(q32, k32, v32, causal, lens_t.long())
     assert relerr(o.view(B, S, H, D), ref) < 4 * EPS16[dtype], "forward"
-    o2, lse2 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens_t if lens else None)  # transpose-read V path
-    assert relerr(o2.view(B, S, H, D), ref) < 4 * EPS16[dtype], "forward v2"
-    assert float((lse2 - lse).abs().max()) < 1e-3
     # lse check on valid rows
     sc = (q32.permute(0, 2, 1, 3) @ k32.permute(0, 2, 3, 1)) / math.sqrt(D)
     ar = torch.arange(S, device=dev())
@@ -265,15 +261,14 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     do = rnd(B * S, H * D, dtype=dtype, seed=9)
     do_masked = do.clone()
     ref.backward(do.float().view(B, S, H, D))
-    dq, dk, dv = ops.attn_bwd(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
     tol = 8 * EPS16[dtype]
-    assert relerr(dv.view(B, S, H, D), v32.grad) < tol, "dv"
-    assert relerr(dk.view(B, S, H, D), k32.grad) < tol, "dk"
-    assert relerr(dq.view(B, S, H, D), q32.grad) < tol, "dq"
     dq2, dk2, dv2 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
-    assert relerr(dv2.view(B, S, H, D), v32.grad) < tol, "dv (v2)"
-    assert relerr(dk2.view(B, S, H, D), k32.grad) < tol, "dk (v2)"
-    assert relerr(dq2.view(B, S, H, D), q32.grad) < tol, "dq (v2)"
+    assert relerr(dv2.view(B, S, H, D), v32.grad) < tol, "dv"
+    assert relerr(dk2.view(B, S, H, D), k32.grad) < tol, "dk"
+    assert relerr(dq2.view(B, S, H, D), q32.grad) < tol, "dq"
+    # the delta/lse scratch is reused across calls: a second call (other data) must not see stale rows
+    dq3, dk3, dv3 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    assert torch.equal(dq3, dq2) and torch.equal(dk3, dk2) and torch.equal(dv3, dv2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -286,10 +281,26 @@ def test_patch_embed_pieces(ops, dtype):
     ref = torch.nn.functional.unfold(pix.to(dtype).float(), ps, stride=ps).transpose(1, 2).reshape(N * G * G, 3 * ps * ps)
     assert torch.equal(cols[:, :588].float(), ref)
     assert float(cols[:, 588:].abs().max()) == 0.0
-    patch, cls, pos = rnd(N * G * G, d, dtype=dtype), rnd(d, dtype=dtype, seed=1), rnd(G * G + 1, d, dtype=dtype, seed=2)
+    # token-major form used by the tower: one zero CLS slot per image, written per image tensor into a shared buffer
+    S = G * G + 1
+    cols2 = torch.full((N * S, kpad), 7.0, dtype=dtype, device=dev())
+    ops.im2col_patches(pix[:1], ps, kpad, dtype, rows_per_img=S, row0=1, out=cols2[:S])
+    ops.im2col_patches(pix[1:], ps, kpad, dtype, rows_per_img=S, row0=1, out=cols2[S:])
+    c3 = cols2.view(N, S, kpad)
+    assert float(c3[:, 0].abs().max()) == 0.0 and torch.equal(c3[:, 1:, :588].reshape(N * G * G, 588).float(), ref)
+    patch, cls, pos = rnd(N * S, d, dtype=dtype), rnd(d, dtype=dtype, seed=1), rnd(S, d, dtype=dtype, seed=2)
     x = ops.vit_assemble(patch, cls, pos, N, G * G)
-    r = torch.cat([cls.float().expand(N, 1, d), patch.float().view(N, G * G, d)], 1) + pos.float()[None]
-    assert relerr(x.view(N, G * G + 1, d), r) < 2 * EPS16[dtype]
+    r = torch.cat([cls.float().expand(N, 1, d), patch.float().view(N, S, d)[:, 1:]], 1) + pos.float()[None]
+    assert relerr(x.view(N, S, d), r) < 2 * EPS16[dtype]
+    # strided 2-D copy / accumulate (K-padding of the patch-embedding weight and of its gradient)
+    w = rnd(d, 588, dtype=dtype, seed=5)
+    wp = torch.zeros(d, kpad, dtype=dtype, device=dev())
+    ops.copy2d(w, wp)
+    assert torch.equal(wp[:, :588], w) and float(wp[:, 588:].abs().max()) == 0.0
+    g = rnd(d, 588, dtype=dtype, seed=6)
+    want = (g.float() + wp[:, :588].float()).to(dtype)
+    ops.copy2d(wp[:, :588], g, accumulate=True)
+    assert torch.equal(g, want)
 
 
 def test_splice_index_and_embed(ops):
@@ -427,9 +438,9 @@ def test_wgrad_tn_any_tokens_splitk(ops, dtype, T, No, Ki):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1000, 515, 256), (613, 4096, 1024),
                                    (2048, 2048, 4096), (300, 103, 64), (4096, 11008, 512)])
-@pytest.mark.parametrize("which", [256, 4, 88])
+@pytest.mark.parametrize("which", [256])
 def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
-    """The pipelined 256x256 kernels (forced: 256 = 8 waves, 4 = 4 waves x 128x128 with AGPR accumulators), incl.
+    """The pipelined 256x256 kernel (forced), incl.
     M/N edges, short K (prologue/tail clamps) and epilogues (direct and LDS-staged); repeated to catch pipeline
     races (results must be bit-identical run to run)."""
     a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)

@@ -27,13 +27,19 @@ def _named(frozen=()):
 @pytest.mark.parametrize("key,fn,frozen", [("vit_llrd", optim.vit_lr_scale, ()), ("llm_llrd", optim.llm_lr_scale, ()), ("plain", None, ()),
                                            ("vit_llrd_frozen_llm", optim.vit_lr_scale, ("model.layers.", "lm_head", "embed_tokens", "model.norm"))])
 def test_param_groups_match_reference(key, fn, frozen):
-    got = optim.param_groups(_named(frozen), GOLD["lr"], GOLD["wd"], fn)
+    from oracle import llrd_ref
+
+    got = llrd_ref.param_groups(_named(frozen), GOLD["lr"], GOLD["wd"], fn)
     ref = GOLD[key]
     assert len(got) == len(ref)
-    for g, r in zip(got, ref):  # same groups, same order, same members, bit-equal lr
+    for g, r in zip(got, ref):  # the oracle restatement: same groups, same order, same members, bit-equal lr
         assert g["names"] == r["names"]
         assert g["weight_decay"] == r["weight_decay"]
         assert g["lr"] == r["lr"]
+    # the product rule (per-parameter lr / weight decay the fused optimizer applies): same assignment as the reference's groups
+    hp = optim.per_param_hparams(_named(frozen), GOLD["lr"], GOLD["wd"], fn)
+    want = {n: (r["lr"], r["weight_decay"]) for r in ref for n in r["names"]}
+    assert hp == want
 
 
 def test_lr_scale_values():

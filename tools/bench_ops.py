@@ -2,6 +2,7 @@
 import sys, os, math, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev_arms")); import dev_ops as D  # needs MH_LIB_PATH=tools/dev_arms/libmerlin_hip_dev.so (python -m merlin_amd.csrc.build --dev)
 from merlin_amd import ops as O
 
 dev = torch.device("cuda:0")
@@ -34,21 +35,21 @@ def bench_attn(B, S, H, D, causal):
     dtype = torch.bfloat16
     qkv = torch.randn(B * S, 3 * H * D, device=dev).to(dtype)
     q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
-    vt = O.attn_prep_v(v, B, S, H, D)
-    o, lse = O.attn_fwd(q, k, vt, B, S, H, D, causal)
-    t = timeit(lambda: O.attn_fwd(q, k, vt, B, S, H, D, causal, out=o, lse=lse))
+    vt = D.attn_prep_v(v, B, S, H, D)
+    o, lse = D.attn_fwd(q, k, vt, B, S, H, D, causal)
+    t = timeit(lambda: D.attn_fwd(q, k, vt, B, S, H, D, causal, out=o, lse=lse))
     fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
     print(f"attn_fwd B={B} S={S} H={H} D={D} causal={causal}: {t*1e3:.3f} ms  {fl/t/1e12:.0f} TFLOP/s", flush=True)
     if hasattr(O, "attn_fwd2"):
         t_ = timeit(lambda: O.attn_fwd2(q, k, v, B, S, H, D, causal, out=o, lse=lse))
         print(f"attn_fwd2 (no prep_v): {t_*1e3:.3f} ms  {fl/t_/1e12:.0f} TFLOP/s", flush=True)
     do = torch.randn(B * S, H * D, device=dev).to(dtype)
-    t2 = timeit(lambda: O.attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal), iters=5, warm=2)
+    t2 = timeit(lambda: D.attn_bwd(q, k, v, o, do, lse, B, S, H, D, causal), iters=5, warm=2)
     print(f"attn_bwd: {t2*1e3:.3f} ms  {2.5*fl/t2/1e12:.0f} TFLOP/s (5 matmuls counted)", flush=True)
     if hasattr(O, "attn_bwd2"):
         t_ = timeit(lambda: O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal), iters=5, warm=2)
         print(f"attn_bwd2 (no re-layout passes): {t_*1e3:.3f} ms  {2.5*fl/t_/1e12:.0f} TFLOP/s", flush=True)
-    t3 = timeit(lambda: O.attn_prep_v(v, B, S, H, D, out=vt))
+    t3 = timeit(lambda: D.attn_prep_v(v, B, S, H, D, out=vt))
     print(f"prep_v: {t3*1e3:.3f} ms  {2*B*S*H*D*2/t3/1e9:.0f} GB/s", flush=True)
 
 

@@ -1,6 +1,7 @@
 // Shared declarations of the attention-backward kernels (see attn_bwd.hip for the design notes).
 #pragma once
 #include "mh_common.h"
+#include "merlin_hip_dev.h"
 
 namespace mhattn {
 

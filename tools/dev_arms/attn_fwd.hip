@@ -25,6 +25,7 @@
 //     (pad_input semantics).  With right padding + causal masking valid rows never see padded keys.
 //   * causal: q-blocks are launched heaviest-first; a wave skips tiles entirely above its diagonal.
 #include "mh_common.h"
+#include "merlin_hip_dev.h"
 
 namespace {
 

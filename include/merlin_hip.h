@@ -187,6 +187,24 @@ int mh_attn_decode_splits(int B, int H, int Smax);
 int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, void* out, const int32_t* lens,
                    int B, int H, int D, int Smax, float* ws, int dt, void* stream);
 
+/* ---- token selection for generate() (HF GenerationMixin as the reference's eval scripts drive it: eval_mmvet.py:101-120
+ * `do_sample=True, temperature=0.2` or `num_beams=5`; site-packages transformers/generation/logits_process.py) ------------
+ * logits fp32 [rows, ldl], V valid columns.  do_sample=0: out[r] = lowest index of the row maximum (greedy).
+ * do_sample=1: TemperatureLogitsWarper (z = logits / temperature) -> TopKLogitsWarper (top_k > 0: keep z >= k-th largest, ties
+ * kept; 0 = off) -> TopPLogitsWarper (top_p < 1: drop tokens whose ascending cumulative probability is <= 1 - top_p, keep >= 1)
+ * -> multinomial over the remaining softmax by inverse CDF in index order.  The uniform of row r at decoding step `step` is
+ * u = (splitmix64(seed ^ splitmix64(step * 0x100000001B3 + r)) >> 40) * 2^-24 (counter-based: nothing comes from the host,
+ * the same (seed, step, row) always draws the same token); out_u (nullable) receives it.  out int64 [rows]. */
+int mh_select_tokens(const float* logits, int64_t ldl, int rows, int V, int do_sample, float temperature, int top_k, float top_p,
+                     uint64_t seed, int64_t step, int64_t* out, float* out_u, void* stream);
+/* out[r, :V] = log_softmax(logits[r, :V]) + row_bias[r] (fp32; row_bias nullable): beam search's accumulated scores
+ * log_probs + running_beam_scores (transformers/generation/utils.py `_beam_search`) */
+int mh_log_softmax_rows(const float* logits, int64_t ldl, int rows, int V, float* out, int64_t ldo, const float* row_bias, void* stream);
+/* dst[i, :cols_bytes] = src[idx[i], :cols_bytes]; row strides and cols in BYTES, all multiples of 16 (KV-cache reorder by
+ * beam index = HF `_reorder_cache`; expansion of a prefilled batch to num_beams rows per prompt) */
+int mh_gather_rows2d(const void* src, int64_t lds_bytes, const int64_t* idx, void* dst, int64_t ldd_bytes, int rows, int64_t cols_bytes,
+                     void* stream);
+
 /* ---- CLIP patch embedding ------------------------------------------------------------- */
 /* cols[n*rows_per_img + row0 + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad; the
  * first row0 rows of every image (the CLS slot when rows_per_img = G*G+1, row0 = 1) are zero, so the token-major layout

@@ -169,9 +169,11 @@ class HipEngine:
         if self.rope is None or self.rope.shape[0] < S or self.rope.device != device:
             # computed on the host exactly like transformers' LlamaRotaryEmbedding (fp32), then uploaded:
             # init-time plumbing; mh_rope_table is the device-side equivalent (tests compare them)
+            from .llama_mmgpt import rope_theta_of
+
             D = cfg.head_dim
             n = max(S, 64)
-            inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+            inv = 1.0 / (rope_theta_of(cfg) ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
             fr = torch.outer(torch.arange(n, dtype=torch.float32), inv)
             self.rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(device)
         return self.rope
@@ -738,6 +740,7 @@ class HipEngine:
             self.v = [torch.zeros(B, Smax, d, dtype=dtype, device=device) for _ in range(n_layers)]
             self.lens = torch.zeros(B, dtype=torch.int32, device=device)
             self.B, self.Smax = B, Smax
+            self.k_alt = self.v_alt = None
 
     def prefill(self, input_ids, attention_mask, images, max_new_tokens, inputs_embeds=None):
         """Full forward over the prompt that also fills a KV cache; returns (logits fp32 [B, V] at each sequence's last
@@ -753,6 +756,35 @@ class HipEngine:
         lens = ctx["lens"]
         cache.lens.copy_(lens if lens is not None else torch.full((B,), S, dtype=torch.int32, device=A.flat.device))
         return logits, cache
+
+    def expand_cache(self, cache, rows):
+        """New cache whose row i is a copy of `cache` row rows[i] (int64 on the device): a prefilled batch expanded to
+        num_beams rows per prompt (the reference: inputs_embeds.repeat_interleave(5), base_mmgpt.py:162-163)."""
+        A = self.arena
+        n = int(rows.numel())
+        Smax, d = cache.Smax, cache.k[0].shape[-1]
+        out = HipEngine.KVCache(0, n, Smax, d, A.flat.dtype, A.flat.device)
+        for li in range(len(cache.k)):
+            for src_l, dst_l in ((cache.k, out.k), (cache.v, out.v)):
+                dst = torch.empty(n, Smax, d, dtype=A.flat.dtype, device=A.flat.device)
+                O.gather_rows2d(src_l[li].view(cache.B, Smax * d), rows, dst.view(n, Smax * d))
+                dst_l.append(dst)
+        out.lens = cache.lens.index_select(0, rows).contiguous()  # B int32 values, once per generate() call
+        return out
+
+    def reorder_cache(self, cache, beam_idx, n_valid):
+        """cache row i <- cache row beam_idx[i] for the first n_valid positions (HF `_reorder_cache` under beam search):
+        one gather kernel per layer and tensor into a second buffer set, then the sets swap."""
+        d = cache.k[0].shape[-1]
+        if getattr(cache, "k_alt", None) is None:
+            cache.k_alt = [torch.empty_like(t) for t in cache.k]
+            cache.v_alt = [torch.empty_like(t) for t in cache.v]
+        n = cache.B
+        for li in range(len(cache.k)):
+            O.gather_rows2d(cache.k[li].view(n, -1), beam_idx, cache.k_alt[li].view(n, -1), cols=n_valid * d)
+            O.gather_rows2d(cache.v[li].view(n, -1), beam_idx, cache.v_alt[li].view(n, -1), cols=n_valid * d)
+        cache.k, cache.k_alt = cache.k_alt, cache.k
+        cache.v, cache.v_alt = cache.v_alt, cache.v
 
     def quantize_decode_weights(self):
         """fp8 (OCP e4m3, one scale per 128 k) copies of the decoder's Linear weights for the decode step (BASELINE cfg 5's

@@ -45,6 +45,28 @@ class CausalLMOutputWithPast:
         return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions) if v is not None)
 
 
+def _check_config(config):
+    """Accepts merlin_amd's own MMGPTConfig or a transformers LlamaConfig subclass (merlin_amd/hf_compat.py): the engine reads
+    vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, rms_norm_eps, rope theta, head_dim."""
+    kv = getattr(config, "num_key_value_heads", None)
+    if kv not in (None, config.num_attention_heads):
+        raise NotImplementedError("GQA is not part of the reference's Llama-7B path")
+    if getattr(config, "hidden_act", "silu") != "silu":
+        raise NotImplementedError("LlamaMLP uses silu")
+    if config.hidden_size % config.num_attention_heads:
+        raise ValueError("hidden_size must be a multiple of num_attention_heads")
+
+
+def rope_theta_of(config) -> float:
+    t = getattr(config, "rope_theta", None)
+    if t is None:  # transformers >= 5: rope_parameters = {"rope_theta": ..., "rope_type": "default"}
+        rp = getattr(config, "rope_parameters", None) or {}
+        if rp.get("rope_type", "default") != "default":
+            raise NotImplementedError("only the default rotary embedding is on the reference's Llama path")
+        t = rp.get("rope_theta", 10000.0)
+    return float(t)
+
+
 class MMGPTLlamaModel(nn.Module):
     """LlamaModel parameter tree (`embed_tokens`, `layers`, `norm`) + vision_tower/projector slots."""
 
@@ -85,6 +107,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
 
     def __init__(self, config):
         super().__init__()
+        _check_config(config)
         self.config = config
         self.model = MMGPTLlamaModel(config)
         self.vocab_size = config.vocab_size
@@ -197,6 +220,16 @@ class MMGPTLlamaForCausalLM(nn.Module):
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         if not self.use_im_start_end and images is not None:
             raise NotImplementedError  # base_mmgpt.py:137
+        beam_rep = 0
+        if self.use_beam_search and images is not None and input_ids is not None and input_ids.shape[1] != 1:
+            # base_mmgpt.py:121,160-163: under use_beam_search HF has already expanded input_ids x num_beams while `images` still
+            # has one entry per prompt; the reference's zip() keeps the first len(images) rows and repeats the spliced
+            # embeddings 5x.  Identical rows give identical logits: compute the kept rows once and repeat the result.
+            beam_rep = 5
+            n_keep = len(images)
+            input_ids = input_ids[:n_keep]
+            attention_mask = attention_mask[:n_keep] if attention_mask is not None else None
+            labels = labels[:n_keep] if labels is not None else None
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters())
         fp8 = bool(getattr(self, "fp8_forward", False))  # opt-in: model.fp8_forward = True (forward / inference only)
         with torch.no_grad():
@@ -206,6 +239,8 @@ class MMGPTLlamaForCausalLM(nn.Module):
             if self._anchor is None or self._anchor.device != loss.device:
                 self._anchor = torch.zeros(1, device=loss.device, requires_grad=True)
             loss = _HipStep.apply(self._anchor, loss, self.engine, ectx)
+        if beam_rep:
+            logits = logits.repeat_interleave(beam_rep, dim=0)
         if not return_dict:
             return ((loss, logits) if loss is not None else (logits,))
         return CausalLMOutputWithPast(loss=loss, logits=logits)
@@ -222,62 +257,16 @@ class MMGPTLlamaForCausalLM(nn.Module):
                              "attention_mask": attention_mask, "images": kwargs.get("images", None)})
         return model_inputs
 
-    @torch.no_grad()
-    def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens=32, eos_token_id=None, do_sample=False,
-                 use_cache=True, num_beams=1, use_graph=True, fp8_weights=False, **kw):
-        """Greedy decoding (eval_mmvet.py:101-120 calls `model.generate(input_ids, images=[...], ...)`).
-        use_cache=True: one prefill over the prompt fills a KV cache, then one HBM-bound decode step per token
-        (llama_mmgpt.py:114-134 semantics: only the last token is fed, images are consumed by the prefill only);
-        use_graph replays the step as one captured HIP graph instead of ~300 separate launches; fp8_weights decodes with
-        fp8 (e4m3, per-128-block scales) copies of the decoder weights - half the bytes per token, the prefill stays 16-bit.
-        use_cache=False: full-sequence recompute per token (kept as the cross-check).  Prompts may be right-padded
-        (attention_mask); finished sequences keep emitting eos.  Sampling and beam search are not implemented."""
-        if do_sample or num_beams != 1:
-            raise NotImplementedError("sampling / beam search are not implemented; greedy only")
-        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
-        if not use_cache:
-            ids = input_ids
-            for _ in range(max_new_tokens):
-                out = self.forward(input_ids=ids, attention_mask=attention_mask, images=images)
-                nxt = out.logits[:, -1, :].argmax(dim=-1, keepdim=True).to(ids.device)
-                ids = torch.cat([ids, nxt], dim=1)
-                if attention_mask is not None:
-                    attention_mask = torch.cat([attention_mask, torch.ones_like(attention_mask[:, :1])], dim=1)
-                if eos is not None and bool((nxt == eos).all()):
-                    break
-            return ids
-        logits, cache = self.engine.prefill(input_ids, attention_mask, images, max_new_tokens)
-        B = input_ids.shape[0]
-        graph = None
-        if use_graph and logits.is_cuda and max_new_tokens > 2:
-            graph, g_tok, g_logits = self.engine.capture_decode_graph(cache, fp8=fp8_weights)  # the decode step as one replayable HIP graph
-        done = torch.zeros(B, dtype=torch.bool, device=logits.device)
-        new = []
-        for step in range(max_new_tokens):
-            nxt = logits.argmax(dim=-1)
-            if eos is not None:
-                nxt = torch.where(done, torch.full_like(nxt, eos), nxt)
-                done = done | (nxt == eos)
-            new.append(nxt)
-            if step + 1 == max_new_tokens or (eos is not None and bool(done.all())):
-                break
-            if graph is not None:
-                g_tok.copy_(nxt)
-                graph.replay()
-                logits = g_logits
-            else:
-                logits = self.engine.decode_step(nxt, cache, fp8=fp8_weights)
-        new = torch.stack(new, dim=1).to(input_ids.device)
-        if attention_mask is None:
-            return torch.cat([input_ids, new], dim=1)
-        # right-padded prompts: the continuation of each row starts at its own length
-        lens = attention_mask.to(torch.bool).sum(dim=1)
-        out = torch.full((B, input_ids.shape[1] + new.shape[1]), self.config.pad_token_id or 0, dtype=input_ids.dtype, device=input_ids.device)
-        for b in range(B):
-            lb = int(lens[b])
-            out[b, :lb] = input_ids[b, :lb]
-            out[b, lb:lb + new.shape[1]] = new[b]
-        return out
+    def generate(self, input_ids, images=None, **kwargs):
+        """HF `generate` as the reference's eval scripts call it (eval_mmvet.py:101-120): greedy, `do_sample=True,
+        temperature=...` (HF warpers: temperature, top_k=50 default, top_p) and `num_beams=5` beam search, with
+        `stopping_criteria`, `max_new_tokens` / `max_length`, eos / pad handling of transformers' GenerationMixin; runs on the
+        engine's prefill + KV-cache decode step (merlin_amd/generation.py).  Extras: use_cache=False (full recompute per token,
+        the cross-check), use_graph (decode step as one HIP graph), fp8_weights (fp8 weight copies for the decode GEMVs),
+        seed (counter-based sampling stream; default drawn from torch's global generator)."""
+        from ..generation import generate as _generate
+
+        return _generate(self, input_ids, images=images, **kwargs)
 
     # ---- construction helpers ----------------------------------------------------------------------
     @classmethod
@@ -285,7 +274,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
         """builder.py:70-74.  Loads config.json and, when present, weights in the reference layout."""
         from ..checkpoint import iter_checkpoint
 
-        config = config if config is not None else MMGPTConfig.from_pretrained(path)
+        config = config if config is not None else cls.config_class.from_pretrained(path)
         model = cls(config)
         own = dict(model.named_parameters())
         for k, v in iter_checkpoint(path, lambda k: k in own) if os.path.isdir(path) else ():

@@ -502,6 +502,39 @@ def copy2d(src, dst, accumulate=False):
     return dst
 
 
+def select_tokens(logits, V=None, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, seed=0, step=0, return_u=False):
+    """logits fp32 [R, >=V] -> next token ids int64 [R]: greedy argmax, or temperature / top-k / top-p multinomial with a
+    counter-based uniform per (seed, step, row) (include/merlin_hip.h: mh_select_tokens)."""
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    out = torch.empty(R, dtype=torch.int64, device=logits.device)
+    u = torch.empty(R, dtype=torch.float32, device=logits.device) if return_u else None
+    L.check(L.lib().mh_select_tokens(p(logits), i64(logits.stride(0)), i32(R), i32(V), i32(int(do_sample)), f32(temperature), i32(top_k),
+                                     f32(top_p), u64(seed & 0xFFFFFFFFFFFFFFFF), i64(step), p(out), p(u), _stream()), "mh_select_tokens")
+    return (out, u) if return_u else out
+
+
+def log_softmax_rows(logits, V=None, row_bias=None):
+    """log_softmax over the first V columns of every row (+ row_bias[r]): fp32 [R, V]."""
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    out = torch.empty(R, V, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().mh_log_softmax_rows(p(logits), i64(logits.stride(0)), i32(R), i32(V), p(out), i64(V), p(row_bias), _stream()), "mh_log_softmax_rows")
+    return out
+
+
+def gather_rows2d(src, idx, dst, cols=None):
+    """dst[i, :cols] = src[idx[i], :cols] for row-major 2-D views (own row strides); idx int64 on the device."""
+    assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1 and idx.dtype == torch.int64
+    cols = src.shape[1] if cols is None else cols
+    es = src.element_size()
+    L.check(L.lib().mh_gather_rows2d(p(src), i64(src.stride(0) * es), p(idx), p(dst), i64(dst.stride(0) * es), i32(idx.numel()),
+                                     i64(cols * es), _stream()), "mh_gather_rows2d")
+    return dst
+
+
 def gather_rows(table, idx, out=None):
     """out[i, :] = table[idx[i], :] (idx int64 on the device): the embedding-gather kernel without a splice table."""
     assert idx.dtype == torch.int64 and table.is_contiguous()

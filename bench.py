@@ -8,10 +8,13 @@ A "step" = one full training step of the hot path on one synthetic interpair bat
 (BASELINE cfg 3/4: B=8 sequences x S=4096 = 6 x 336-px frames + trajectory text, ViT-L/14 + mlp
 projector + Llama-7B, random-init weights from the build's generator, bf16):
     forward (ViT -> projector -> splice -> 32 decoder layers -> lm_head -> shifted CE)
-    + backward (all weight gradients, layer recompute as in the reference's gradient checkpointing)
+    + backward (all weight gradients; activations stay resident in the 288 GB of HBM by default, --recompute switches to
+      the reference's per-layer gradient checkpointing)
     + [N>1] bucketed RCCL all-reduce of the 14 GB gradient arena, overlapped with the backward
-    + fused AdamW over the parameter arena.
+    + global-norm clipping + fused AdamW (LLRD groups, cosine schedule) over the parameter arena.
 Inputs are resident in HBM before the timed region.  value = N * B * S / (max-over-ranks step time).
+After the timed training steps the same batch is also timed FORWARD-ONLY (`forward_only` in the JSON line: the north star's
+">= 40 % of the bf16 MFMA roofline on the fused ViT+LLM forward" is quoted on that leg).
 One JSON line is printed by rank 0, with `roofline` (dominant kernel = the MFMA GEMM, timed per launch with
 HIP events on the launch stream inside the timed steps) and `cpu_baseline` (the CPU oracle = a port of the
 reference's CPU forward, timed on this box's host cores on a bounded sample).
@@ -95,6 +98,7 @@ def main():
     ap.add_argument("--recompute", action="store_true", help="recompute each layer's forward in backward (the reference's "
                     "gradient checkpointing) instead of keeping activations resident in the 288 GB of HBM")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--no-forward-leg", action="store_true", help="skip the extra forward-only timing after the training steps")
     ap.add_argument("--fp8-forward", action="store_true", help="with --fwd-only: decoder Linears on the scaled-fp8 MFMA (e4m3 operands, "
                     "per-row scales); NOT the headline configuration (dtype field says so)")
     args = ap.parse_args()
@@ -180,7 +184,29 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = O.profile_stop()
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    # ---- forward-only leg (same batch, same weights; not part of `value`) ----
+    fwd_ms = None
+    if not args.fwd_only and not args.no_forward_leg:
+        nf = max(3, min(10, args.steps))
+        with torch.no_grad():
+            for _ in range(2):
+                model(**dbatch)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            tf0 = time.perf_counter()
+            for _ in range(nf):
+                model(**dbatch)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            fwd_dt = time.perf_counter() - tf0
+        if world > 1:
+            t = torch.tensor([fwd_dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fwd_dt = float(t)
+        fwd_ms = fwd_dt / nf * 1e3
     n_tok = int(batch["attention_mask"].sum())  # the metric counts sequence positions, padding excluded
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -225,6 +251,10 @@ def main():
                      "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r01_gemm_traffic.json)", "launches": n,
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
     }
+    if fwd_ms is not None:
+        line["forward_only"] = {"ms_per_step": round(fwd_ms, 2), "tokens_per_s_per_gpu": round(n_tok / (fwd_ms * 1e-3), 1),
+                                "useful_tflops_per_gpu": round(fwd / (fwd_ms * 1e-3) / 1e12, 1),
+                                "mfma_roofline_frac": round(fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
     if not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline()

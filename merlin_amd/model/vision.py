@@ -19,29 +19,7 @@ import torch.nn as nn
 from . import modules as M
 from .config import CLIPVisionConfig
 
-OPENAI_CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
-OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
-
-
-class CLIPImageProcessor:
-    """Minimal stand-in for transformers.CLIPImageProcessor (only what data plumbing reads:
-    crop_size / image_mean / image_std and a tensor `preprocess`).  CPU-side, not on the hot path."""
-
-    def __init__(self, size=336):
-        self.crop_size = {"height": size, "width": size}
-        self.size = {"shortest_edge": size}
-        self.image_mean, self.image_std = OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
-
-    def preprocess(self, image, return_tensors="pt"):
-        x = torch.as_tensor(image, dtype=torch.float32)
-        if x.dim() == 3 and x.shape[-1] == 3:
-            x = x.permute(2, 0, 1)
-        if x.max() > 2:
-            x = x / 255.0
-        x = torch.nn.functional.interpolate(x[None], size=(self.crop_size["height"], self.crop_size["width"]), mode="bicubic", align_corners=False)[0]
-        mean = torch.tensor(self.image_mean).view(3, 1, 1)
-        std = torch.tensor(self.image_std).view(3, 1, 1)
-        return {"pixel_values": [(x - mean) / std]}
+from ..image_processing import CLIPImageProcessor  # noqa: E402,F401  (the data path's processor: base_dataset.py:178-197)
 
 
 def _load_vision_config(name_or_cfg):

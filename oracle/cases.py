@@ -27,6 +27,12 @@ def full_cfg():
     return OracleConfig()
 
 
+def released_cfg():
+    """Geometry of the released checkpoint (pretrain.sh:6-9, README.md:79-80): CLIP-L/14 at 448 px (32x32 patch grid),
+    conv projector stride 2 -> P = 256 image tokens, real widths (1024 / 4096 / 11008, vocab 32003), 2 layers per tower."""
+    return OracleConfig(num_hidden_layers=2, v_num_hidden_layers=2, v_image_size=448, projector="conv", conv_stride=2)
+
+
 def get_case(name):
     if name.startswith("tiny"):
         cfg = tiny_cfg("conv", 2) if name == "tiny_conv2" else tiny_cfg()
@@ -53,4 +59,6 @@ def get_case(name):
         return medium_cfg(), synth.single_image_batch()
     if name == "full_cfg1":
         return full_cfg(), synth.single_image_batch()
+    if name == "released_conv448":
+        return released_cfg(), synth.single_image_batch(P=256, image_size=448, n_caption=24, seed=5, img_seed=6)
     raise KeyError(name)

@@ -208,6 +208,8 @@ if __name__ == "__main__":
                 run_case(n)
         elif g == "medium":
             run_case("medium_cfg1", want_grads=True, logits_slice=(slice(None), slice(None, None, 8), slice(0, 512)))
+        elif g == "released":
+            run_case("released_conv448", want_grads=True, logits_slice=(slice(None), slice(None, None, 4), slice(0, 512)))
         elif g == "full":
             run_case("full_cfg1", want_grads=False, logits_slice=(slice(None), slice(None, None, 16), slice(0, 256)))
         else:

@@ -1,0 +1,309 @@
+"""The reference's CALLERS on the HIP path, end to end on the GPU:
+  * builder.py:70-163 replayed call by call on a reference-layout sharded checkpoint (Auto-class resolution, freeze rules,
+    `.to(dtype, device)`), logits / loss / gradients vs the CPU oracle fed from the same weights, then the eval-style generate;
+  * the released checkpoint's geometry (448 px, conv stride 2, P = 256; pretrain.sh:6-9) at real widths vs the reference golden;
+  * packers + collator + image preprocessing output fed straight into the HIP forward vs the oracle;
+  * `encode_images` / tower / projector module surface incl. the conv projector;
+  * device-side input validation (out-of-range ids / labels, non-right-padded masks)."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+VT = "model.vision_tower.vision_tower.vision_model."
+
+
+def _relerr(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def _write_reference_layout_checkpoint(path, cfg, P, n_shards=3):
+    """config.json (model_type mmgpt) + pytorch_model-0000i-of-0000n.bin + index, keys = the released checkpoint's names."""
+    os.makedirs(path, exist_ok=True)
+    json.dump(dict(model_type="mmgpt", architectures=["MMGPTLlamaForCausalLM"], vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                   intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                   num_key_value_heads=cfg.num_attention_heads, rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=4096,
+                   bos_token_id=1, eos_token_id=2), open(os.path.join(path, "config.json"), "w"))
+    names = list(P)
+    wm = {}
+    for i in range(n_shards):
+        fn = f"pytorch_model-{i + 1:05d}-of-{n_shards:05d}.bin"
+        part = {k: P[k].detach().to(torch.float16).clone() for k in names[i::n_shards]}
+        torch.save(part, os.path.join(path, fn))
+        wm.update({k: fn for k in part})
+    json.dump({"metadata": {}, "weight_map": wm}, open(os.path.join(path, "pytorch_model.bin.index.json"), "w"))
+    clip = os.path.join(path, "clip")
+    os.makedirs(clip, exist_ok=True)
+    json.dump(dict(hidden_size=cfg.v_hidden_size, intermediate_size=cfg.v_intermediate_size, num_hidden_layers=cfg.v_num_hidden_layers,
+                   num_attention_heads=cfg.v_num_attention_heads, image_size=cfg.v_image_size, patch_size=cfg.v_patch_size,
+                   layer_norm_eps=cfg.v_layer_norm_eps), open(os.path.join(clip, "config.json"), "w"))
+    return clip
+
+
+class _Tok:
+    """Tokenizer of a TRAINED checkpoint: the three image tokens already exist (add_tokens returns 0, builder.py:98 resize is a no-op)."""
+
+    def __init__(self, base):
+        self.names = {"<im_patch>": base, "<im_start>": base + 1, "<im_end>": base + 2}
+        self.n = base + 3
+        self.pad_token = self.unk_token = "<unk>"
+
+    def add_tokens(self, toks, special_tokens=True):
+        return sum(t not in self.names for t in toks)
+
+    def __len__(self):
+        return self.n
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.names[t] for t in toks]
+
+
+@pytest.mark.parametrize("projector,case", [("mlp", "tiny_2img"), ("conv", "tiny_conv2")])
+def test_builder_flow_on_reference_layout_checkpoint(tmp_path, projector, case):
+    from transformers import AutoModelForCausalLM
+
+    from merlin_amd import hf_compat  # noqa: F401  (registers "mmgpt")
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+
+    cfg, batch = C.get_case(case)
+    P = R.make_params(cfg, seed=0, requires_grad=False)
+    path = str(tmp_path / "ckpt")
+    clip = _write_reference_layout_checkpoint(path, cfg, P)
+    # ---- builder.py:70-74 ----
+    model = AutoModelForCausalLM.from_pretrained(path)
+    assert type(model).__name__ == "MMGPTLlamaForCausalLM"
+    tok = _Tok(cfg.vocab_size - 3)
+    model.resize_token_embeddings(len(tok))                       # :98
+    model.enable_input_require_grads()                            # :102-103 (gradient_checkpointing)
+    margs = types.SimpleNamespace(vision_tower=clip, vision_select_layer=-2, vision_select_feature="patch", freeze_vision_tower=False,
+                                  conv_stride=cfg.conv_stride, model_name_or_path=path, projector=projector, freeze_projector=False,
+                                  use_im_start_end=True, freeze_lm_model=True)
+    dargs = types.SimpleNamespace(use_beam_search=False)
+    targs = types.SimpleNamespace(device="cuda", gradient_checkpointing=True, bf16=False, fp16=True)
+    model.requires_grad_(False)                                   # :131-132 freeze_lm_model
+    model.build_vision_tokenizer(model_args=margs, data_args=dargs, training_args=targs, tokenizer=tok)  # :135-140
+    assert dargs.image_token_len == cfg.num_patches and dargs.use_im_start_end and dargs.image_processor is not None
+    inner = model.get_model()
+    inner.vision_tower.requires_grad_(not margs.freeze_vision_tower)                                   # :145
+    inner.vision_tower.vision_tower.vision_model.encoder.layers[-1].requires_grad_(False)            # :147
+    inner.vision_tower.vision_tower.vision_model.post_layernorm.requires_grad_(False)                # :148
+    inner.projector.requires_grad_(not margs.freeze_projector)                                         # :153
+    for p in model.get_input_embeddings().parameters():                                                # :157-160
+        p.requires_grad = True
+    for p in model.get_output_embeddings().parameters():
+        p.requires_grad = False
+    model.to(dtype=torch.float16, device="cuda")                                                      # :163
+    assert (model.im_patch_token, model.im_start_token, model.im_end_token) == (cfg.im_patch_token, cfg.im_start_token, cfg.im_end_token)
+    # every tensor came out of the checkpoint files
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.float().cpu(), P[k].to(torch.float16).float()), k
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    assert "model.embed_tokens.weight" in trainable and "model.projector.projector.weight" in trainable and "lm_head.weight" not in trainable
+    assert not any(k.startswith("model.layers.") for k in trainable)
+    last = f"{VT}encoder.layers.{cfg.v_num_hidden_layers - 1}."
+    assert not any(k.startswith(last) or "post_layernorm" in k for k in trainable) and (VT + "encoder.layers.0.mlp.fc1.weight") in trainable
+    # ---- one training forward / backward vs the oracle with the same freeze ----
+    dev = dict(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+               images=[im.cuda() for im in batch["images"]])
+    out = model(**dev)
+    out.loss.backward()
+    Pg = {k: (v.clone().requires_grad_(k in trainable)) for k, v in P.items()}
+    loss_ref, logits_ref = R.forward(Pg, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    m = batch["attention_mask"]
+    assert _relerr(out.logits.float().cpu()[m], logits_ref.detach()[m]) < 2e-3
+    assert abs(float(out.loss) - float(loss_ref)) < 1e-3 * float(loss_ref)
+    for k, p in model.named_parameters():
+        if k not in trainable:
+            assert p.grad is None, k
+            continue
+        gr = Pg[k].grad
+        if gr is None or float(gr.abs().max()) == 0.0 or k.endswith("k_proj.bias"):
+            continue
+        a, b = p.grad.float().cpu().reshape(-1).double(), gr.reshape(-1).double()
+        cos = float(a @ b / (a.norm() * b.norm()))
+        assert cos > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 0.01, (k, cos)
+    # ---- eval_mmvet.py:101-120 ----
+    n_prompt = int((batch["input_ids"][0] == cfg.im_end_token).nonzero()[-1]) + 2
+    ids = batch["input_ids"][:1, :n_prompt].cuda()
+    stops = []
+    o = model.generate(ids, images=dev["images"][:1], do_sample=True, temperature=0.2, max_new_tokens=8, seed=11,
+                       stopping_criteria=[lambda i, s, **kw: stops.append(i.shape[1]) or False])
+    assert o.shape[1] <= n_prompt + 8 and torch.equal(o[:, :n_prompt], ids) and stops == list(range(n_prompt + 1, o.shape[1] + 1))
+    # ---- module surface (base_mmgpt.py:18-21): encode_images = projector(vision_tower(images)) ----
+    feats = model.encode_images([im.cuda().half() for im in batch["images"]])
+    with torch.no_grad():
+        ref = R.encode_images(P, cfg, batch["images"])
+    assert len(feats) == len(ref)
+    for f, r in zip(feats, ref):
+        assert tuple(f.shape) == tuple(r.shape) and _relerr(f.float().cpu(), r) < 3e-3
+    # save in the reference layout and reload the tower slice by prefix (clip_encoder.py:26-62)
+    out_dir = str(tmp_path / "saved")
+    model.save_pretrained(out_dir)
+    from merlin_amd.checkpoint import iter_checkpoint
+
+    saved = dict(iter_checkpoint(out_dir))
+    assert set(saved) == set(P) and all(torch.equal(saved[k].float(), model.state_dict()[k].float().cpu()) for k in saved)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_released_geometry_448px_conv_stride2_vs_reference_golden(dtype):
+    """CLIP-L/14 at 448 px (32 x 32 grid, 1025 tokens), conv projector k3 stride 2 -> P = 256, real widths (pretrain.sh:6-9):
+    logits slice / loss / gradient digests vs the REAL reference's outputs (tests/golden/released_conv448.npz)."""
+    from oracle import cases as C
+    from test_model_gpu import TOL, _build, _to_dev
+
+    tol = TOL[dtype]
+    cfg, batch = C.get_case("released_conv448")
+    g = np.load(os.path.join(GOLD, "released_conv448.npz"))
+    model = _build(cfg, dtype)
+    assert model.data_args.image_token_len == 256
+    out = model(**_to_dev(batch))
+    lg = out.logits.float()
+    err = np.abs(lg[:, ::4, :512].cpu().numpy() - g["logits_slice"]).max() / float(g["logits_absmax"])
+    assert err < tol["logits"], err
+    assert abs(float(out.loss) - float(g["loss"])) < tol["loss"] * abs(float(g["loss"]))
+    out.loss.backward()
+    bad = []
+    for k, p in model.named_parameters():
+        key = f"grad/{k}/norm"
+        if key not in g.files or float(g[key]) == 0.0 or k.endswith("self_attn.k_proj.bias"):
+            continue
+        f = p.grad.float().reshape(-1)
+        stride = max(1, f.numel() // 257)
+        samp = f[::stride][:512].cpu().numpy().astype(np.float64)
+        ref = g[f"grad/{k}/strided"].astype(np.float64)
+        cos = float(samp @ ref / max(1e-30, np.linalg.norm(samp) * np.linalg.norm(ref)))
+        ratio = float(f.double().norm()) / float(g[key])
+        cmin, rtol = (0.999, 0.01) if dtype == torch.float16 else ((0.80 if k == "lm_head.weight" else 0.99), 0.05)
+        if cos < cmin or abs(ratio - 1) > rtol:
+            bad.append((k, cos, ratio))
+    assert not bad, bad[:8]
+
+
+def test_packers_collator_and_image_preprocessing_feed_the_hip_forward():
+    """N1: scripted samples -> InterPairPacker / PairPacker / InterleavePacker (+ process_image('resize'), pretrain.sh:38) ->
+    collate -> model(**batch) on the GPU, against the oracle on the very same batch (one sample per packer; the shorter ones are
+    right-padded, one has no image and carries the zeros image)."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    from PIL import Image
+    from toy_tokenizer import ToyTokenizer
+
+    from merlin_amd import image_processing as IP
+    from merlin_amd import packers as PK
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+    from test_model_gpu import _build
+
+    base = C.tiny_cfg()
+    import dataclasses
+
+    cfg = dataclasses.replace(base, vocab_size=32003, im_patch_token=32000, im_start_token=32001, im_end_token=32002)
+    tok = ToyTokenizer(400)
+    pc = PK.PackerConfig(image_token_len=cfg.num_patches, image_size=cfg.v_image_size)
+    proc = IP.CLIPImageProcessor(size=cfg.v_image_size)
+    rng = np.random.RandomState(3)
+
+    def img(h, w):
+        return IP.process_image(Image.fromarray(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)), proc, cfg.v_image_size, "resize")
+
+    s0 = PK.InterPairPacker(tok, pc)([("<image>\n<image>\nwhere does the car go", "it moves left then stops"), ("<image>\nand now", "it is gone")],
+                                     [img(80, 120), img(64, 64), img(30, 90)])
+    s1 = PK.PairPacker(tok, pc)([(None, "plain text without any picture at all")], [])
+    s2 = PK.InterleavePacker(tok, pc)(["a first sentence", "a second one about a dog", "the end of the document"], [img(50, 70), img(90, 40)], [0, 2])
+    assert len(s0["image"]) == 3 and len(s1["image"]) == 1 and float(s1["image"][0].abs().max()) == 0.0 and len(s2["image"]) == 2
+    batch = PK.collate([s0, s1, s2], tok.pad_token_id, tok.model_max_length)
+    assert batch["input_ids"].shape[0] == 3 and not bool(batch["attention_mask"].all())
+    # the host-side splice table equals what the device kernel builds
+    model = _build(cfg, torch.float16)
+    out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+                images=[im.cuda() for im in batch["images"]])
+    P = R.make_params(cfg, seed=0)
+    with torch.no_grad():
+        loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    m = batch["attention_mask"]
+    assert _relerr(out.logits.float().cpu()[m], logits_ref[m]) < 2e-3
+    assert abs(float(out.loss) - float(loss_ref)) < 1e-3 * float(loss_ref)
+    src_host = PK.splice_table(batch["input_ids"], [len(x["image"]) for x in (s0, s1, s2)], cfg.num_patches, 32001, 32002)
+    from merlin_amd import ops as O
+
+    err = torch.zeros(10, dtype=torch.int32, device="cuda")
+    off = torch.tensor([0, 3, 4, 6], dtype=torch.int32, device="cuda")
+    src_dev = O.splice_index(batch["input_ids"].cuda(), off, cfg.num_patches, 32000, 32001, 32002, err)
+    assert torch.equal(src_dev.cpu(), src_host) and int(err.abs().sum()) == 0
+
+
+def test_device_side_input_validation_raises_like_torch():
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_padbatch")
+    model = _build(cfg, torch.float16)
+    b = _to_dev(batch)
+    model(**b)  # fine
+    bad = dict(b, input_ids=b["input_ids"].clone())
+    bad["input_ids"][1, 1] = cfg.vocab_size + 5
+    with pytest.raises(IndexError):
+        model(**bad)
+    bad = dict(b, labels=b["labels"].clone())
+    bad["labels"][0, 4] = cfg.vocab_size
+    with pytest.raises(IndexError):
+        model(**bad)
+    am = b["attention_mask"].clone()
+    short = int(am.sum(1).argmin())
+    n = int(am[short].sum())
+    am[short, 0] = False  # left padding / a hole: not a dense prefix any more
+    with pytest.raises(ValueError):
+        model(**dict(b, attention_mask=am))
+    am = b["attention_mask"].clone()
+    am[short, n - 2] = False
+    with pytest.raises(ValueError):
+        model(**dict(b, attention_mask=am))
+    model.engine.strict_checks = False
+    model(**dict(b, attention_mask=am))  # opt-out: treated as a dense prefix (documented)
+    model.engine.strict_checks = True
+    model(**b)
+
+
+def test_fp8_weight_copies_follow_the_weights():
+    """fp8 copies cached on the engine must be rebuilt after an optimizer step / load."""
+    from merlin_amd.optim import FusedAdamW
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_1img")
+    llama_dims_ok = cfg.hidden_size % 128 == 0 and cfg.intermediate_size % 128 == 0
+    assert llama_dims_ok
+    model = _build(cfg, torch.bfloat16)
+    b = _to_dev(batch)
+    model.fp8_forward = True
+    with torch.no_grad():
+        l0 = model(**b).logits.clone()
+    model.fp8_forward = False
+    v0 = model.engine.weight_version
+    model(**b).loss.backward()
+    opt = FusedAdamW(model.engine, lr=5e-2)
+    opt.step()
+    opt.zero_grad()
+    assert model.engine.weight_version > v0 and model.engine._fp8_fwd is None
+    model.fp8_forward = True
+    with torch.no_grad():
+        l1 = model(**b).logits
+    model.fp8_forward = False
+    with torch.no_grad():
+        l16 = model(**b).logits
+    assert float((l1 - l0).abs().max()) > 1e-3, "fp8 forward still sees the old weights"
+    assert float((l1 - l16).abs().max()) < 0.2 * float(l16.abs().max())
+    # freeze / unfreeze is picked up by the optimizer's run table
+    model.get_model().layers[0].requires_grad_(False)
+    model(**b).loss.backward()
+    before = model.get_model().layers[0].mlp.up_proj.weight.detach().clone()
+    opt.step()
+    assert torch.equal(model.get_model().layers[0].mlp.up_proj.weight.detach(), before)

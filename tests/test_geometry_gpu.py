@@ -1,0 +1,315 @@
+"""Parity AT THE BENCHMARK'S OWN GEOMETRY (BASELINE cfg 2 / cfg 3 / cfg 5 shapes), which the small op tests do not reach:
+  * flash attention forward / backward at S = 4096, D = 128 causal (64 key tiles, lazy rescale) and ragged, vs a chunked fp32
+    torch reference;
+  * the MFMA GEMM at M = 32 768 tokens in its three operand layouts (NT forward, NN dgrad, TN wgrad incl. the 27 696-token
+    split-K CLIP wgrad) vs fp32 on sampled output tiles;
+  * one interpair sequence S = 4096 x 6 frames (and the S = 8192 interleave layout of cfg 5) through a 2+2-layer REAL-WIDTH
+    model vs the CPU oracle: logits, loss and gradient cosines;
+  * full-depth 7B (24-layer ViT-L + 32-layer Llama) forward + BACKWARD at cfg 2 vs the CPU oracle's autograd (the oracle's
+    forward is pinned to the reference's full-size golden; its backward is torch autograd of that same graph);
+  * the data-parallel path's real branch (RCCL process group of one rank, side stream + events) bit-identical to the plain step.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPS = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
+
+
+def _relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _attn_ref_chunked(q, k, v, do, causal, lens, chunk=512):
+    """fp32 reference with autograd, computed in query chunks (S = 4096 scores of one head fit easily; several heads do not)."""
+    B, S, H, D = q.shape
+    q, k, v = (t.float().clone().requires_grad_() for t in (q, k, v))
+    outs = []
+    ar = torch.arange(S, device=q.device)
+    for b in range(B):
+        kb, vb = k[b].permute(1, 0, 2), v[b].permute(1, 0, 2)  # [H, S, D]
+        ob = []
+        for s0 in range(0, S, chunk):
+            qs = q[b, s0:s0 + chunk].permute(1, 0, 2)
+            sc = (qs @ kb.transpose(1, 2)) / (D ** 0.5)
+            mask = ar[None, :] >= lens[b]
+            if causal:
+                mask = mask | (ar[None, :] > ar[s0:s0 + chunk, None])
+            p = torch.softmax(sc.masked_fill(mask[None], float("-inf")), -1)
+            p = torch.nan_to_num(p, nan=0.0)
+            o = (p @ vb).permute(1, 0, 2)
+            o = o.masked_fill((ar[s0:s0 + chunk] >= lens[b])[:, None, None], 0.0)
+            ob.append(o)
+        outs.append(torch.cat(ob, 0))
+    out = torch.stack(outs, 0)
+    out.backward(do.float())
+    return out.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,D,causal,lens", [(1, 4096, 4, 128, True, None), (2, 4096, 2, 128, True, [3900, 4096]),
+                                                  (1, 8192, 2, 128, True, None), (48, 577, 2, 64, False, None)])
+def test_attention_at_benchmark_sequence_lengths(dtype, B, S, H, D, causal, lens):
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(B * S + H)
+    qkv = torch.randn(B * S, 3 * H * D, generator=g, device="cuda").to(dtype)
+    q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
+    do = torch.randn(B * S, H * D, generator=g, device="cuda").to(dtype)
+    lt = torch.tensor(lens if lens else [S] * B, dtype=torch.int32, device="cuda")
+    o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lt if lens else None)
+    dq, dk, dv = O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=lt if lens else None)
+    nb = min(B, 3)  # reference on the first rows of a big image batch (same kernels, same shapes)
+    sl = slice(0, nb * S)
+    ro, rq, rk, rv = _attn_ref_chunked(q[sl].reshape(nb, S, H, D), k[sl].reshape(nb, S, H, D), v[sl].reshape(nb, S, H, D),
+                                       do[sl].reshape(nb, S, H, D), causal, lt[:nb].long())
+    assert _relerr(o[sl].view(nb, S, H, D), ro) < 4 * EPS[dtype], "o"
+    tol = 8 * EPS[dtype]
+    assert _relerr(dv[sl].view(nb, S, H, D), rv) < tol, "dv"
+    assert _relerr(dk[sl].view(nb, S, H, D), rk) < tol, "dk"
+    assert _relerr(dq[sl].view(nb, S, H, D), rq) < tol, "dq"
+    assert torch.isfinite(o.float()).all() and torch.isfinite(dq.float()).all()
+
+
+def _sample_tiles(M, N, n=6, t=96, seed=0):
+    rng = np.random.RandomState(seed)
+    out = [(0, 0), (M - t, N - t), (M - t, 0)]
+    for _ in range(n):
+        out.append((int(rng.randint(0, M - t)), int(rng.randint(0, N - t))))
+    return out, t
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(32768, 12288, 4096), (32768, 4096, 11008), (32768, 22016, 4096)])
+def test_gemm_at_cfg3_token_count_three_layouts(dtype, M, N, K):
+    """M = B*S = 32 768 tokens.  NT: x W^T (forward, qkv / down / gate|up shapes), NN: dy W (dgrad, W read K-strided),
+    TN: dy^T x (wgrad, both operands K-strided, contraction over the 32 768 tokens)."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g, device="cuda") * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(dtype)
+    y = O.gemm_nt(x, w)
+    tiles, t = _sample_tiles(M, N)
+    for (r, c) in tiles:
+        ref = x[r:r + t].float() @ w[c:c + t].float().t()
+        assert _relerr(y[r:r + t, c:c + t], ref) < 3 * EPS[dtype], ("NT", r, c)
+    # dgrad: dx[M, K] = dy[M, N] @ W[N, K]
+    dy = (torch.randn(M, N, generator=g, device="cuda") * 0.5).to(dtype)
+    dx = O.gemm_nt(dy, w, b_t=True)
+    tiles, t = _sample_tiles(M, K, seed=1)
+    for (r, c) in tiles:
+        ref = dy[r:r + t].float() @ w[:, c:c + t].float()
+        assert _relerr(dx[r:r + t, c:c + t], ref) < 3 * EPS[dtype], ("NN", r, c)
+    # wgrad: dW[N, K] = dy^T @ x, fp32 accumulate over 32 768 tokens, then accumulate-into (second micro-batch)
+    dw = torch.empty(N, K, dtype=dtype, device="cuda")
+    O.wgrad_tn(dy, x, dw, accum=False)
+    tiles, t = _sample_tiles(N, K, seed=2)
+    for (r, c) in tiles:
+        ref = dy[:, r:r + t].float().t() @ x[:, c:c + t].float()
+        assert _relerr(dw[r:r + t, c:c + t], ref) < 3 * EPS[dtype], ("TN", r, c)
+    dw2 = dw.clone()
+    O.wgrad_tn(dy, x, dw2, accum=True)
+    r, c = tiles[3]
+    assert _relerr(dw2[r:r + t, c:c + t], 2 * dw[r:r + t, c:c + t].float()) < 3 * EPS[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_clip_wgrad_at_cfg3_image_token_count(dtype):
+    """48 frames x 577 tokens = 27 696 rows (not a multiple of the 64-row K tile): split-K wgrads of the tower's four shapes."""
+    from merlin_amd import ops as O
+
+    T = 48 * 577
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for No, Ki in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096), (1024, 640)):
+        dy = (torch.randn(T, No, generator=g, device="cuda") * 0.3).to(dtype)
+        x = (torch.randn(T, Ki, generator=g, device="cuda") * 0.3).to(dtype)
+        out = torch.empty(No, Ki, dtype=dtype, device="cuda")
+        O.wgrad_tn(dy, x, out, accum=False)
+        ref = dy.float().t() @ x.float()
+        assert _relerr(out, ref) < 3 * EPS[dtype], (No, Ki)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _real_width_2layer(dtype):
+    from oracle import cases as C
+    from test_model_gpu import _build
+
+    cfg = C.medium_cfg()  # ViT d=1024 / 16 heads / 336 px, Llama d=4096 / 32 heads / ff 11008 / vocab 32003, 2 layers each
+    return cfg, _build(cfg, dtype)
+
+
+def _grad_report(model, P, names):
+    bad = []
+    for k in names:
+        a = dict(model.named_parameters())[k].grad.float().cpu().reshape(-1).double()
+        b = P[k].grad.reshape(-1).double()
+        cos = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-300))
+        bad.append((k, cos, float(a.norm() / b.norm())))
+    return bad
+
+
+@pytest.mark.parametrize("layout", ["interpair_S4096_6frames", "interleave_S8192_4images"])
+def test_packed_sequence_at_benchmark_length_vs_oracle(layout):
+    """One sequence of BASELINE cfg 3 (1 + 6 x 582 + 602 + 1 = 4096 positions, 6 x 336 px frames) resp. cfg 5 (S = 8192,
+    4 images spread through the text) through the real-width 2+2-layer model, fp16 (BASELINE's 1e-3 row applies to shallow
+    models), forward + backward vs the fp32 CPU oracle."""
+    import psutil
+
+    from merlin_amd import synth
+    from oracle import ref_cpu as R
+
+    if psutil.virtual_memory().available < 80e9:
+        pytest.skip("the fp32 CPU oracle materialises [32, S, S] attention scores: needs ~60 GB of free host memory at S = 8192")
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    dtype = torch.float16
+    cfg, model = _real_width_2layer(dtype)
+    if layout.startswith("interpair"):
+        batch = synth.interpair_batch(B=1, S=4096)
+        assert batch["input_ids"].shape == (1, 4096) and batch["images"][0].shape[0] == 6
+    else:
+        batch = synth.interleave_batch(B=1, S=8192, n_images=4)
+        assert batch["input_ids"].shape == (1, 8192) and batch["images"][0].shape[0] == 4
+    out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+                images=[im.cuda() for im in batch["images"]])
+    out.loss.backward()
+    names = ["lm_head.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight",
+             "model.layers.0.self_attn.v_proj.weight", "model.layers.0.mlp.gate_proj.weight", "model.layers.0.input_layernorm.weight",
+             "model.projector.projector.weight", "model.vision_tower.vision_tower.vision_model.encoder.layers.0.self_attn.q_proj.weight",
+             "model.vision_tower.vision_tower.vision_model.encoder.layers.0.mlp.fc1.weight",
+             "model.vision_tower.vision_tower.vision_model.embeddings.patch_embedding.weight",
+             "model.vision_tower.vision_tower.vision_model.embeddings.position_embedding.weight"]
+    P = {k: p.detach().float().cpu() for k, p in model.named_parameters()}  # the generator's bits (checked in test_model_gpu)
+    with_grads = layout.startswith("interpair")  # S = 8192: forward only (the oracle's saved [32, S, S] probabilities would not fit)
+    if with_grads:
+        for k in names:
+            P[k].requires_grad_(True)
+    with torch.set_grad_enabled(with_grads):
+        loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    err = _relerr(out.logits.float().cpu(), logits_ref.detach())
+    print(f"[{layout}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} oracle {float(loss_ref):.5f}")
+    assert err < 2e-3, err
+    assert abs(float(out.loss) - float(loss_ref)) < 1e-3 * float(loss_ref)
+    if with_grads:
+        loss_ref.backward()
+        rep = _grad_report(model, P, names)
+        print(rep)
+        assert all(c > 0.999 and abs(r - 1) < 0.01 for _, c, r in rep), rep
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])  # cfg 2's dtype; the fp16 full-depth FORWARD is pinned in test_model_gpu
+def test_full_depth_7b_backward_vs_oracle(dtype):
+    """BASELINE cfg 2 ("bf16 forward+backward ..., vs CPU ref within tol") at FULL depth: the 24-layer ViT-L + 32-layer Llama-7B
+    backward of the HIP path against the CPU oracle's autograd on the host cores, for parameters at the start, middle and end of
+    both towers (their gradients pass through every layer above them).  Needs ~70 GB of host RAM for the fp32 oracle."""
+    import psutil
+
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+    from test_model_gpu import _build
+
+    if psutil.virtual_memory().available < 80e9:
+        pytest.skip("needs ~70 GB of free host memory for the fp32 CPU oracle of the 7B model")
+    cfg, batch = C.get_case("full_cfg1")
+    model = _build(cfg, dtype)
+    out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+                images=[im.cuda() for im in batch["images"]])
+    out.loss.backward()
+    VT = "model.vision_tower.vision_tower.vision_model."
+    names = ["lm_head.weight", "model.norm.weight", "model.layers.31.mlp.down_proj.weight", "model.layers.31.self_attn.q_proj.weight",
+             "model.layers.16.mlp.up_proj.weight", "model.layers.16.self_attn.o_proj.weight", "model.layers.0.self_attn.v_proj.weight",
+             "model.layers.0.mlp.gate_proj.weight", "model.layers.0.input_layernorm.weight", "model.projector.projector.weight",
+             VT + "encoder.layers.22.mlp.fc2.weight", VT + "encoder.layers.11.self_attn.out_proj.weight", VT + "encoder.layers.0.self_attn.q_proj.weight",
+             VT + "encoder.layers.0.layer_norm1.weight", VT + "embeddings.patch_embedding.weight", VT + "embeddings.class_embedding"]
+    # the oracle's parameters are the device model's bits (generator weights, exactly representable in both 16-bit types)
+    P = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+    for k in names:
+        P[k].requires_grad_(True)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    err = _relerr(out.logits.float().cpu(), logits_ref.detach())
+    rep = _grad_report(model, P, names)
+    print(f"[full depth {dtype}] logits rel err {err:.3e} loss {float(out.loss):.5f} vs {float(loss_ref):.5f}")
+    for r in rep:
+        print("   ", r)
+    cmin, rtol = (0.995, 0.02) if dtype == torch.float16 else (0.95, 0.08)
+    bad = [r for r in rep if not (r[1] > cmin and abs(r[2] - 1) < rtol)]
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_data_parallel_real_branch_on_one_gpu_is_bit_identical():
+    """merlin_amd/dp.py's CUDA branch (RCCL process group, side stream, events, 35+ bucket all-reduces) has to execute
+    somewhere: a process group of ONE rank on this GPU, GradSync(force=True).  The all-reduce of one rank is the identity, so
+    gradients, the clip coefficient and the post-step parameters must be bit-identical to the plain step; then two
+    micro-batches under accumulate() reduce only once."""
+    import torch.distributed as dist
+
+    from merlin_amd.dp import GradSync
+    from merlin_amd.optim import FusedAdamW, vit_lr_scale
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_padbatch")
+    b = _to_dev(batch)
+
+    def run(sync_mode):
+        model = _build(cfg, torch.bfloat16)
+        opt = FusedAdamW(model.engine, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
+        sync = GradSync(model.engine, force=True) if sync_mode else None
+        for step in range(2):
+            model(**b).loss.backward()
+            opt.step(grad_scale=(sync.grad_scale if sync else 1.0), max_grad_norm=1.0)
+            g = model.engine.arena.gflat.clone()
+            opt.zero_grad()
+        return model, g, sync
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m0, g0, _ = run(False)
+        m1, g1, sync = run(True)
+        assert sync.active and sync.world == 1 and sync.comm_stream is not None
+        n_buckets = len(sync.order)
+        A = m1.engine.arena
+        covered = sum(n for _, n in sync.order)
+        trainable = sum(A.params[n].numel() for n in A.names if A.params[n].requires_grad and "post_layernorm" not in n
+                        and f"encoder.layers.{cfg.v_num_hidden_layers - 1}." not in n)
+        assert n_buckets == 1 + cfg.num_hidden_layers + 1 + 1 + (cfg.v_num_hidden_layers - 1) + 1, sync.order
+        assert covered >= trainable and sync.n_collectives == 2 * n_buckets
+        assert torch.equal(g0, g1), "gradients differ with the bucketed all-reduce in the loop"
+        assert torch.equal(m0.engine.arena.flat, m1.engine.arena.flat), "parameters differ after two optimizer steps"
+        # gradient accumulation: 2 micro-steps, ONE round of collectives, sum of both micro-batches
+        before = sync.n_collectives
+        for i in range(2):
+            with sync.accumulate(i, 2):
+                m1(**b).loss.backward()
+        assert sync.n_collectives == before + n_buckets
+        acc = m1.engine.arena.gflat.clone()
+        for p in m1.parameters():
+            p.grad = None
+        m1(**b).loss.backward()
+        single = m1.engine.arena.gflat
+        assert _relerr(acc, 2 * single.float()) < 1e-2
+        with pytest.raises(RuntimeError):
+            m1(**b).loss.backward()  # accumulating onto reduced gradients without no_sync()
+        # a text-only batch still reports every bucket in the same order (fixed collective sequence across ranks)
+        for p in m1.parameters():
+            p.grad = None
+        order = list(sync.order)
+        tb = dict(input_ids=b["input_ids"][:, :8].clone(), attention_mask=None, labels=b["labels"][:, :8].clone(), images=None)
+        tb["input_ids"][tb["input_ids"] >= cfg.vocab_size - 3] = 5
+        tb["labels"][:] = tb["input_ids"]
+        m1(**tb).loss.backward()
+        assert sync.order == order
+        VT = "model.vision_tower.vision_tower.vision_model."
+        assert float(m1.engine.arena.gview(VT + "encoder.layers.0.mlp.fc1.weight").abs().max()) == 0.0
+        assert float(m1.engine.arena.gview("model.projector.projector.weight").abs().max()) == 0.0
+    finally:
+        dist.destroy_process_group()

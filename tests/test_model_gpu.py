@@ -15,7 +15,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = {torch.float16: dict(logits=2e-3, loss=1e-3, cos=0.999, norm=0.01),
+# fp16 = BASELINE.json's "within 1e-3 rel fp16" row: asserted at 1e-3 on the tiny fixtures (measured 7.6e-4 .. 9.3e-4, tools/measure_parity.py);
+# at real widths 16-bit storage alone costs more (medium 1.5e-3, released geometry 1.2e-3): those are asserted at 2e-3 here and at
+# 1e-3 in the fp32-store parity mode (tests/test_parity_mode_gpu.py)
+TOL = {torch.float16: dict(logits=2e-3, logits_tiny=1e-3, loss=1e-3, cos=0.999, norm=0.01),
        torch.bfloat16: dict(logits=1.5e-2, loss=5e-3, cos=0.995, norm=0.03)}
 
 
@@ -60,7 +63,7 @@ def test_tiny_forward_backward_parity(name, dtype):
     mask = batch["attention_mask"].numpy()
     ref = g["logits"]
     err = np.abs(logits - ref)[mask].max() / np.abs(ref[mask]).max()
-    assert err < tol["logits"], f"logits rel err {err}"
+    assert err < tol.get("logits_tiny", tol["logits"]), f"logits rel err {err}"
     assert abs(float(out.loss) - float(g["loss"])) < tol["loss"] * abs(float(g["loss"]))
     # padded query rows: the flash path returns finite values (zeros from attention)
     assert np.isfinite(logits).all()

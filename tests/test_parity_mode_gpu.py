@@ -1,0 +1,93 @@
+"""BASELINE.json: "producing logits within 1e-3 rel fp16 of the reference CPU path on identical inputs".  With 16-bit activation
+storage that bound is met on the shallow fixtures only (tools/measure_parity.py: tiny 7.6e-4 .. 9.3e-4, real widths 1.2e-3 ..
+2.0e-3, full depth 4.6e-3 - rounding of the stored activations, profiles/r01_full_depth_rounding_attribution.txt).  The
+fp32-store parity mode (merlin_amd/parity.py, SURVEY §8d cfg 2) removes exactly that rounding and nothing else - same splice,
+same GEMM kernel, same weights - and is held to 1e-3 at EVERY size here: the reference goldens (tiny, medium, released
+geometry, full 7B depth) and the CPU oracle at the benchmark's sequence lengths."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3
+
+
+def _run(name, dtype):
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    m = _build(cfg, dtype)
+    m.engine.parity_fp32 = True
+    with torch.no_grad():
+        out = m(**_to_dev(batch))
+    return cfg, batch, g, out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", ["tiny_1img", "tiny_2img", "tiny_padbatch", "tiny_textonly", "tiny_conv2"])
+def test_parity_mode_tiny(name, dtype):
+    cfg, batch, g, out = _run(name, dtype)
+    mask = batch["attention_mask"].numpy()
+    lg = out.logits.float().cpu().numpy()
+    err = np.abs(lg - g["logits"])[mask].max() / np.abs(g["logits"][mask]).max()
+    print(f"[parity {name} {dtype}] logits rel err {err:.3e}")
+    assert err < TOL, err
+    assert abs(float(out.loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+
+
+@pytest.mark.parametrize("name,step,width", [("medium_cfg1", 8, 512), ("released_conv448", 4, 512), ("full_cfg1", 16, 256)])
+def test_parity_mode_real_widths_and_full_depth(name, step, width):
+    """medium (2+2 layers, real widths), the released 448 px / conv-s2 geometry, and the FULL 24-layer ViT-L + 32-layer Llama-7B
+    of BASELINE cfg 1/2, against the REAL reference's fp32 outputs."""
+    cfg, batch, g, out = _run(name, torch.bfloat16)
+    lg = out.logits.float()
+    err = np.abs(lg[:, ::step, :width].cpu().numpy() - g["logits_slice"]).max() / float(g["logits_absmax"])
+    print(f"[parity {name}] logits rel err {err:.3e}  loss {float(out.loss):.6f} ref {float(g['loss']):.6f}")
+    assert err < TOL, err
+    lse = torch.logsumexp(lg, dim=-1).cpu().numpy()
+    assert np.abs(lse - g["logits_lse"]).max() < 10 * TOL
+    assert abs(float(out.loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+
+
+@pytest.mark.parametrize("layout", ["interpair_S4096_6frames", "interleave_S8192_4images"])
+def test_parity_mode_at_benchmark_sequence_lengths(layout):
+    import psutil
+
+    from merlin_amd import synth
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+    from test_model_gpu import _build
+
+    if psutil.virtual_memory().available < 80e9:
+        pytest.skip("fp32 CPU oracle at S = 8192 needs ~60 GB of free host memory")
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    cfg = C.medium_cfg()
+    model = _build(cfg, torch.bfloat16)
+    model.engine.parity_fp32 = True
+    batch = synth.interpair_batch(B=1, S=4096) if layout.startswith("interpair") else synth.interleave_batch(B=1, S=8192, n_images=4)
+    with torch.no_grad():
+        out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+                    images=[im.cuda() for im in batch["images"]])
+        P = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+        loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    err = float((out.logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max())
+    print(f"[parity {layout}] logits rel err {err:.3e}  loss {float(out.loss):.6f} oracle {float(loss_ref):.6f}")
+    assert err < TOL, err
+    assert abs(float(out.loss) - float(loss_ref)) < 1e-4 * float(loss_ref)
+
+
+def test_parity_mode_is_forward_only_and_off_by_default():
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_1img")
+    m = _build(cfg, torch.bfloat16)
+    assert m.engine.parity_fp32 is False
+    m.engine.parity_fp32 = True
+    with pytest.raises(RuntimeError):
+        m(**_to_dev(batch))  # grad-enabled training forward: refused

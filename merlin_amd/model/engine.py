@@ -445,6 +445,80 @@ class HipEngine:
         _, act = O.gemm_fp8_swiglu_fwd(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype)
         return O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
 
+    # ---- fp8 TRAINING step (BASELINE cfg 5: "fp8 MFMA weight path"; no reference counterpart) -------------
+    # Every decoder Linear - forward, dgrad and wgrad - runs on the scaled-fp8 MFMA as an NT product of two ROW-quantised
+    # e4m3 operands (include/merlin_hip.h, "fp8 TRAINING step"): activations / gradients are quantised dynamically per row
+    # (per token for forward and dgrad, per feature - on the transposed copy - for wgrad), weights per output channel (W8)
+    # and per input channel (WT8 = rowquant(W^T)), re-quantised once per weight version.  Residual stream, norms, RoPE,
+    # attention, SwiGLU, the CLIP tower, lm_head + CE and all gradient accumulators stay 16-bit / fp32 as in the bf16 step.
+    def fp8_train_weights(self, li):
+        def make():
+            out = []
+            for W in self.llama:
+                out.append(dict(wqkv=O.quant_fp8_rows(W.wqkv), wo=O.quant_fp8_rows(W.wo), wgu=O.quant_fp8_rows(W.wgu), wd=O.quant_fp8_rows(W.wd),
+                                wqkvT=O.quant_fp8_rows_t(W.wqkv), woT=O.quant_fp8_rows_t(W.wo), wguT=O.quant_fp8_rows_t(W.wgu),
+                                wdT=O.quant_fp8_rows_t(W.wd)))
+            return out
+        return self._derive("fp8_train_weights", make)[li]
+
+    def _llama_layer_fwd_fp8_train(self, W, li, x, B, S, lens, keep):
+        cfg = self.model.config
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        Q = self.fp8_train_weights(li)
+        h1 = O.rmsnorm_fwd(x, W.ln1, eps)
+        qkv = O.gemm_fp8_rope(O.quant_fp8_rows(h1), Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+        x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
+        h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+        gu, act = O.gemm_fp8_swiglu_fwd(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype)
+        y = O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
+        return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
+
+    def _wgrad_fp8(self, dy, x, gout, fresh):
+        """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as column-scaled transposed e4m3 copies
+        (contraction over the tokens, zero-padded to a multiple of 128)."""
+        O.gemm_fp8(O.quant_fp8_rows_t(dy), O.quant_fp8_rows_t(x), out=gout, accum=not fresh)
+
+    def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
+        cfg = self.model.config
+        A = self.arena
+        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        if saved is None:
+            _, saved = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=True)
+        h1, qkv, o, lse, x2, h2, gu, act = saved
+        Q = self.fp8_train_weights(li)
+        p = W.p
+        acc = not fresh
+        train = self._trainable(p + "mlp.down_proj.weight")
+        dt = x.dtype
+        dgu = O.gemm_fp8_swiglu_bwd(O.quant_fp8_rows(dy), Q["wdT"], gu)  # SwiGLU backward in the dgrad's store phase
+        if train:
+            self._wgrad_fp8(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh)
+        del act, gu
+        dh2 = O.gemm_fp8(O.quant_fp8_rows(dgu), Q["wguT"], out_dtype=dt)
+        if train:
+            self._wgrad_fp8(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)
+        del dgu
+        dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
+                            dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
+        do = O.gemm_fp8(O.quant_fp8_rows(dx2), Q["woT"], out_dtype=dt)
+        if train:
+            self._wgrad_fp8(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:], rope=self.rope)
+        dh1 = O.gemm_fp8(O.quant_fp8_rows(dqkv), Q["wqkvT"], out_dtype=dt)
+        if train:
+            self._wgrad_fp8(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh)
+        dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
+                           dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
+        if train:
+            self._ready(W.names)
+        return dx
+
     def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
         A = self.arena
@@ -596,13 +670,23 @@ class HipEngine:
         del feats
         # ---- decoder ----
         xs, saves = [], []
-        if fp8:
+        fp8_train = fp8 == "train"
+        ctx["fp8_train"] = fp8_train
+        if fp8 and (d % 128 or cfg.intermediate_size % 128):
+            raise RuntimeError("the fp8 GEMM path needs hidden and intermediate sizes that are multiples of 128")
+        if fp8 and not fp8_train:
             if want_grad:
-                raise RuntimeError("the fp8 GEMM path is forward-only (no backward through fp8 operands)")
-            if d % 128 or cfg.intermediate_size % 128:
-                raise RuntimeError("fp8 forward needs hidden and intermediate sizes that are multiples of 128")
+                raise RuntimeError("model.fp8_forward is the inference form (forward only); set model.fp8_training = True for the fp8 training step")
             F8 = getattr(self, "_fp8_fwd", None) or self.quantize_forward_weights()
         for li, W in enumerate(self.llama):
+            if fp8_train:
+                if kv_cache is not None:
+                    raise RuntimeError("prefill runs the 16-bit or fp8-forward path")
+                if want_grad:
+                    xs.append(x)
+                x, sv = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=want_grad and self.save_activations)
+                saves.append(sv)
+                continue
             if fp8:
                 x = self._llama_layer_fwd_fp8(W, F8[li], x, B, S, lens,
                                               kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None)
@@ -673,7 +757,10 @@ class HipEngine:
         ctx["hn"] = ctx["x_last"] = None
         # ---- decoder ----
         for i in reversed(range(len(self.llama))):
-            dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
+            if ctx.get("fp8_train"):
+                dx = self._llama_layer_bwd_fp8(self.llama[i], i, ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
+            else:
+                dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
             ctx["xs"][i] = None
             ctx["saves"][i] = None
         # ---- embedding + splice ----

@@ -231,7 +231,9 @@ class MMGPTLlamaForCausalLM(nn.Module):
             attention_mask = attention_mask[:n_keep] if attention_mask is not None else None
             labels = labels[:n_keep] if labels is not None else None
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters())
-        fp8 = bool(getattr(self, "fp8_forward", False))  # opt-in: model.fp8_forward = True (forward / inference only)
+        # opt-in fp8 paths (BASELINE cfg 5's fp8 MFMA weight path): model.fp8_training = True -> forward + backward GEMMs of the decoder
+        # on the scaled-fp8 MFMA; model.fp8_forward = True -> the inference form (forward only, weights quantised once)
+        fp8 = "train" if getattr(self, "fp8_training", False) else bool(getattr(self, "fp8_forward", False))
         if getattr(self.engine, "parity_fp32", False) and inputs_embeds is None:
             # fp32-store parity forward (merlin_amd/parity.py): measures the kernels against BASELINE's 1e-3, forward only
             if want_grad:

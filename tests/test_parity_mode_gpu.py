@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 1e-3
+TOL = 1e-4  # BASELINE asks for 1e-3; measured 6e-7 .. 4.5e-6 (profiles/r02_parity.txt), so hold the kernels to 10x tighter
 
 
 def _run(name, dtype):

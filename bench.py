@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md), not the 2:1-sparse figure
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak
 
 LLAMA_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
                 rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192)
@@ -90,9 +91,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2", "cfg3-ragged", "cfg5-bf16"],
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2", "cfg3-ragged", "cfg5", "cfg5-bf16"],
                     help="cfg3 = BASELINE metric config (default); cfg3-ragged = same with ragged lengths + key padding; "
-                         "cfg5-bf16 = cfg 5's S=8192 interleave shape with bf16 weights (the fp8 weight path is not built)")
+                         "cfg5 = BASELINE configs[4]: S=8192 interleave (4 images + long text), decoder GEMMs (forward, dgrad, wgrad) on the "
+                         "fp8 MFMA weight path; cfg5-bf16 = the same shape with bf16 weights")
+    ap.add_argument("--fp8-train", action="store_true", help="run the chosen config with the fp8 training step (cfg5 implies it)")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recompute", action="store_true", help="recompute each layer's forward in backward (the reference's "
@@ -129,6 +132,8 @@ def main():
     if args.fp8_forward:
         assert args.fwd_only, "--fp8-forward is forward-only"
         model.fp8_forward = True
+    if args.fp8_train:
+        model.fp8_training = True
     if args.config == "cfg3":
         B = args.batch or 8
         batch = synth.interpair_batch(B=B, S=4096, rank=rank)
@@ -137,10 +142,14 @@ def main():
         B = args.batch or 8
         batch = synth.interpair_batch(B=B, S=4096, rank=rank, ragged=True)
         workload = f"interpair ragged: B={B}/GPU, lengths <= 4096 right-padded (key-padding branch), 6 frames, ViT-L/14-336 + mlp + Llama-7B"
-    elif args.config == "cfg5-bf16":
+    elif args.config in ("cfg5", "cfg5-bf16"):
         B = args.batch or 4
         batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
-        workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
+        if args.config == "cfg5":
+            args.fp8_train = True
+            workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers"
+        else:
+            workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
     else:
         B = 1
         batch = synth.single_image_batch()
@@ -226,20 +235,23 @@ def main():
     value = tokens / (dt / args.steps)
     fwd = algorithmic_flops_fwd(B, S, n_img)
     useful = fwd * (1.0 if args.fwd_only else 3.0)
-    n, work, gms = prof.get("gemm_nt", (0, 0.0, 1e-9))
+    fp8_dom = "gemm_fp8" in prof and prof["gemm_fp8"][2] > prof.get("gemm_nt", (0, 0.0, 0.0))[2]
+    n, work, gms = prof.get("gemm_fp8" if fp8_dom else "gemm_nt", (0, 0.0, 1e-9))
     ach = work / (gms * 1e-3) / 1e12
+    peak = PEAK_FP8_TFLOPS if fp8_dom else PEAK_BF16_TFLOPS
     # HBM/fabric traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass of this same command
     # (PMC collection cannot run inside the timed process); the committed summary is read back here.
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as f:
-            traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e9, 3) if args.config == "cfg3" and not args.fwd_only else None
+            traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e9, 3) if args.config == "cfg3" and not args.fwd_only and not args.fp8_train else None
     except Exception:
         traffic = None
     line = {
         "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else "bf16"),
+        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
+                                                                                          "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
                    "step": "fwd only" if args.fwd_only else "fwd+bwd" + (" (layer recompute)" if args.recompute else " (activations resident)") + "+allreduce+adamw",
@@ -247,8 +259,9 @@ def main():
         "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_nt_256/gemm_nt_128 (bf16 MFMA GEMM, all launches)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r01_gemm_traffic.json)", "launches": n,
+        "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "gemm_nt_256/gemm_nt_128 (bf16 MFMA GEMM, all launches)"),
+                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r01_gemm_traffic.json)", "launches": n,
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
     }
     if fwd_ms is not None:

@@ -132,8 +132,6 @@ def main():
     if args.fp8_forward:
         assert args.fwd_only, "--fp8-forward is forward-only"
         model.fp8_forward = True
-    if args.fp8_train:
-        model.fp8_training = True
     if args.config == "cfg3":
         B = args.batch or 8
         batch = synth.interpair_batch(B=B, S=4096, rank=rank)
@@ -154,6 +152,8 @@ def main():
         B = 1
         batch = synth.single_image_batch()
         workload = "single 336px image + 32-token caption (S=613), ViT-L/14-336 + mlp projector + Llama-7B"
+    if args.fp8_train:
+        model.fp8_training = True
     S = batch["input_ids"].shape[1]
     n_img = sum(int(im.shape[0]) for im in batch["images"])
     dbatch = dict(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),

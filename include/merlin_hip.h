@@ -114,6 +114,11 @@ int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const v
  * uints of scratch.  mh_gemm_fp8 accepts MH_EPI_ACCUM (gradient accumulation into the 16-bit gradient arena).
  * mh_gemm_fp8_swiglu_bwd: dgu = swiglu_bwd(gu, dy Wd) with WdT8 = rowquant(down_proj.weight^T) [ff, d_model]. */
 int mh_quant_fp8_rows_t(const void* x, int64_t ldx, void* qt, int64_t ldq, float* scales, unsigned* amax_ws, int R, int C, int dt, void* stream);
+/* Single-pass form used by the training step for activations / gradients: the transposed copy is scaled by a [C] vector the
+ * caller provides - in practice ONE tensor-wide scale, the maximum of the tensor's row scales (mh_max_to_vec fills out[0..m)
+ * with max_i s[i]), which mh_quant_fp8_rows already produced: no column-maximum pass over the data. */
+int mh_quant_fp8_t_scaled(const void* x, int64_t ldx, void* qt, int64_t ldq, const float* scales, int R, int C, int dt, void* stream);
+int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream);
 int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* gu,
                            int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);

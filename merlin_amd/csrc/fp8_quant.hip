@@ -78,7 +78,42 @@ __global__ __launch_bounds__(256) void quant_fp8_transposed_k(const uint16_t* __
   }
 }
 
+// out[0..m) = max(1e-30.., max_i s[i]): the tensor-wide scale of a row-quantised tensor = the largest of its row scales
+__global__ __launch_bounds__(1024) void max_to_vec_k(const float* __restrict__ s, int n, float* __restrict__ out, int m) {
+  __shared__ float red[16];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) v = fmaxf(v, s[i]);
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t = fmaxf(t, red[i]);
+  if (!(t > 0.f)) t = 1.0f;
+  for (int i = threadIdx.x; i < m; i += 1024) out[i] = t;
+}
+
 }  // namespace
+
+// Transposed e4m3 copy with ONE scale for the whole tensor (scales[0]; the caller fills the [C] vector the GEMM reads with
+// it: mh_max_to_vec): a single pass, 3 bytes of traffic per element.  e4m3 keeps its 3-bit mantissa over 2^15 of range, so
+// a tensor-wide scale costs precision only for columns more than ~4 decades below the tensor maximum.
+extern "C" int mh_quant_fp8_t_scaled(const void* x, int64_t ldx, void* qt, int64_t ldq, const float* scales, int R, int C, int dt, void* stream) {
+  if (!x || !qt || !scales || R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldq & 15) || !aligned16(x) || !aligned16(qt)) return MH_ERR_ARG;
+  if (ldq < (int64_t)(R + 127) / 128 * 128) return MH_ERR_ARG;
+  const dim3 g2((C + 63) / 64, (R + 127) / 128);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(quant_fp8_transposed_k<MH_BF16>, g2, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, scales, (uint8_t*)qt, ldq, R, C);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(quant_fp8_transposed_k<MH_F16>, g2, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, scales, (uint8_t*)qt, ldq, R, C);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+extern "C" int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream) {
+  if (!s || !out || n <= 0 || m <= 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(max_to_vec_k, dim3(1), dim3(1024), 0, as_stream(stream), s, n, out, m);
+  MH_LAUNCH_CHECK();
+}
 
 // x [R, C] (16-bit, row stride ldx elements) -> qt [C, ldq bytes] with ldq >= round_up(R, 128) (columns R.. of qt up to the
 // next multiple of 128 are zero-filled), scales [C]; amax_ws: C uints of scratch (zeroed here).

@@ -467,19 +467,24 @@ class HipEngine:
         eps = cfg.rms_norm_eps
         Q = self.fp8_train_weights(li)
         h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-        qkv = O.gemm_fp8_rope(O.quant_fp8_rows(h1), Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
+        a1 = O.quant_fp8_rows(h1)
+        qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
-        x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
+        a2 = O.quant_fp8_rows(o)
+        x2 = O.gemm_fp8(a2, Q["wo"], out_dtype=x.dtype, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-        gu, act = O.gemm_fp8_swiglu_fwd(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype)
-        y = O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
-        return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
+        a3 = O.quant_fp8_rows(h2)
+        gu, act = O.gemm_fp8_swiglu_fwd(a3, Q["wgu"], out_dtype=x.dtype)
+        a4 = O.quant_fp8_rows(act)
+        y = O.gemm_fp8(a4, Q["wd"], out_dtype=x.dtype, resid=x2)
+        # the row scales (one float per token) are kept: their maximum is the tensor-wide scale of the transposed wgrad operand
+        return y, ((h1, qkv, o, lse, x2, h2, gu, act, (a1[1], a2[1], a3[1], a4[1])) if keep else None)
 
-    def _wgrad_fp8(self, dy, x, gout, fresh):
-        """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as column-scaled transposed e4m3 copies
-        (contraction over the tokens, zero-padded to a multiple of 128)."""
-        O.gemm_fp8(O.quant_fp8_rows_t(dy), O.quant_fp8_rows_t(x), out=gout, accum=not fresh)
+    def _wgrad_fp8(self, dy, sdy, x, sx, gout, fresh):
+        """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as transposed e4m3 copies (contraction over the
+        tokens, zero-padded to a multiple of 128), each scaled by its tensor-wide scale = the largest of its row scales."""
+        O.gemm_fp8(O.quant_fp8_t_from_rows(dy, sdy), O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
 
     def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
@@ -488,31 +493,36 @@ class HipEngine:
         eps = cfg.rms_norm_eps
         if saved is None:
             _, saved = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=True)
-        h1, qkv, o, lse, x2, h2, gu, act = saved
+        h1, qkv, o, lse, x2, h2, gu, act, (s_h1, s_o, s_h2, s_act) = saved
         Q = self.fp8_train_weights(li)
         p = W.p
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
         dt = x.dtype
-        dgu = O.gemm_fp8_swiglu_bwd(O.quant_fp8_rows(dy), Q["wdT"], gu)  # SwiGLU backward in the dgrad's store phase
+        dy8 = O.quant_fp8_rows(dy)
+        dgu = O.gemm_fp8_swiglu_bwd(dy8, Q["wdT"], gu)  # SwiGLU backward in the dgrad's store phase
         if train:
-            self._wgrad_fp8(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh)
-        del act, gu
-        dh2 = O.gemm_fp8(O.quant_fp8_rows(dgu), Q["wguT"], out_dtype=dt)
+            self._wgrad_fp8(dy, dy8[1], act, s_act, A.gview(p + "mlp.down_proj.weight"), fresh)
+        del act, gu, dy8
+        dgu8 = O.quant_fp8_rows(dgu)
+        dh2 = O.gemm_fp8(dgu8, Q["wguT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)
-        del dgu
+            self._wgrad_fp8(dgu, dgu8[1], h2, s_h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)
+        del dgu, dgu8
         dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
                             dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
-        do = O.gemm_fp8(O.quant_fp8_rows(dx2), Q["woT"], out_dtype=dt)
+        dx28 = O.quant_fp8_rows(dx2)
+        do = O.gemm_fp8(dx28, Q["woT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh)
+            self._wgrad_fp8(dx2, dx28[1], o, s_o, A.gview(p + "self_attn.o_proj.weight"), fresh)
+        del dx28
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:], rope=self.rope)
-        dh1 = O.gemm_fp8(O.quant_fp8_rows(dqkv), Q["wqkvT"], out_dtype=dt)
+        dqkv8 = O.quant_fp8_rows(dqkv)
+        dh1 = O.gemm_fp8(dqkv8, Q["wqkvT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh)
+            self._wgrad_fp8(dqkv, dqkv8[1], h1, s_h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh)
         dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
                            dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
         if train:

@@ -278,6 +278,18 @@ def quant_fp8_rows_t(x):
     return qt, sc
 
 
+def quant_fp8_t_from_rows(x, row_scales):
+    """x [R, C] (16-bit) -> (qt uint8 [C, round_up(R, 128)], s fp32 [C] = one tensor-wide scale, the largest of x's row scales
+    as produced by quant_fp8_rows): the transposed operand of the wgrad GEMMs in ONE pass over x."""
+    R, C_ = x.shape
+    Rp = round_up(R, 128)
+    qt = torch.empty(C_, Rp, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(C_, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mh_max_to_vec(p(row_scales), i32(row_scales.numel()), p(sc), i32(C_), _stream()), "mh_max_to_vec")
+    L.check(L.lib().mh_quant_fp8_t_scaled(p(x), i64(_rowmajor(x)), p(qt), i64(Rp), p(sc), i32(R), i32(C_), i32(dt_of(x)), _stream()), "mh_quant_fp8_t_scaled")
+    return qt, sc
+
+
 def gemm_fp8_swiglu_bwd(dy8, wdt8, gu):
     """dgu = swiglu_bwd(gu, dy Wd) on the scaled-fp8 MFMA; dy8 = rowquant(dy) [T, d], wdt8 = rowquant(Wd^T) [ff, d]."""
     (qa, sa), (qb, sb) = dy8, wdt8

@@ -42,6 +42,22 @@ def test_transposed_row_quantisation(dtype, R, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,C", [(300, 256), (4096, 1024)])
+def test_transposed_quantisation_with_tensor_scale(dtype, R, C):
+    """The single-pass form of the training step: one scale for the whole tensor = the largest row scale of its row-quantised twin."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(R)
+    x = (torch.randn(R, C, generator=g, device="cuda") * 2).to(dtype)
+    q, s_row = O.quant_fp8_rows(x)
+    qt, s = O.quant_fp8_t_from_rows(x, s_row)
+    assert float(s.min()) == float(s.max()) == float(s_row.max()) == float(x.float().abs().max() / 448.0)
+    q_ref = (x.float() * (1.0 / s[0])).t().contiguous().to(torch.float8_e4m3fn)
+    assert torch.equal(qt[:, :R].view(torch.float8_e4m3fn).float(), q_ref.float())
+    assert int(qt[:, R:].max()) == 0 if qt.shape[1] > R else True
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T,No,Ki", [(512, 256, 384), (1000, 512, 256), (4096, 4096, 1024), (32768, 1024, 4096)])
 def test_fp8_dgrad_and_wgrad_products(dtype, T, No, Ki):
     """dgrad dx = dy W and wgrad dW = dy^T x as NT products of row-quantised operands: exact against the dequantised operands'

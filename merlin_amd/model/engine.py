@@ -483,8 +483,11 @@ class HipEngine:
 
     def _wgrad_fp8(self, dy, sdy, x, sx, gout, fresh):
         """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as transposed e4m3 copies (contraction over the
-        tokens, zero-padded to a multiple of 128), each scaled by its tensor-wide scale = the largest of its row scales."""
-        O.gemm_fp8(O.quant_fp8_t_from_rows(dy, sdy), O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
+        tokens, zero-padded to a multiple of 128).  The GRADIENT operand is scaled per output feature (column maxima: a pass
+        over dy - the q / k / v thirds of dqkv differ by orders of magnitude, a tensor-wide scale flushes the small ones to
+        zero, measured); the ACTIVATION operand (norm outputs, attention output, SwiGLU output: homogeneous columns) by its
+        tensor-wide scale = the largest of the row scales its forward quantisation already produced (single pass)."""
+        O.gemm_fp8(O.quant_fp8_rows_t(dy), O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
 
     def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config

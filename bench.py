@@ -95,7 +95,6 @@ def main():
                     help="cfg3 = BASELINE metric config (default); cfg3-ragged = same with ragged lengths + key padding; "
                          "cfg5 = BASELINE configs[4]: S=8192 interleave (4 images + long text), decoder GEMMs (forward, dgrad, wgrad) on the "
                          "fp8 MFMA weight path; cfg5-bf16 = the same shape with bf16 weights")
-    ap.add_argument("--overlap-wgrad", type=int, default=None, help="1/0: decoder weight-gradient GEMMs on a second HIP stream (default: the engine's default)")
     ap.add_argument("--fp8-train", action="store_true", help="run the chosen config with the fp8 training step (cfg5 implies it)")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,8 +129,6 @@ def main():
     assert O.arch_ok(local_rank), "bench.py needs a gfx950 (MI355X) device"
     model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
     model.engine.save_activations = not args.recompute
-    if args.overlap_wgrad is not None:
-        model.engine.overlap_wgrad = bool(args.overlap_wgrad)
     if args.fp8_forward:
         assert args.fwd_only, "--fp8-forward is forward-only"
         model.fp8_forward = True

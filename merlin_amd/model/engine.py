@@ -53,10 +53,6 @@ class HipEngine:
         self.on_backward_begin = None  # callable(fresh: bool) | None
         self.strict_checks = True
         self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
-        # decoder weight-gradient GEMMs on a second HIP stream: they are off the backward's critical path (nothing in the
-        # layer consumes dW), so their blocks fill the tail rounds of the dgrad GEMMs and run under the HBM-bound norm kernels
-        self.overlap_wgrad = False
-        self._wg_stream = None
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -198,35 +194,6 @@ class HipEngine:
     def _ready(self, names):
         if self.on_grads_ready is not None:
             self.on_grads_ready(names)
-
-    def _wgrad_side(self, dy, x, gout, fresh, Tpad):
-        """_wgrad on the side stream (overlap_wgrad): returns the event that marks its completion, or None when it ran inline.
-        The operands are recorded on the side stream so the caching allocator does not hand their memory out early."""
-        if not self.overlap_wgrad or not dy.is_cuda:
-            self._wgrad(dy, x, gout, fresh, Tpad)
-            return None
-        main = torch.cuda.current_stream(dy.device)
-        if self._wg_stream is None or self._wg_stream.device != dy.device:
-            self._wg_stream = torch.cuda.Stream(device=dy.device)
-        side = self._wg_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._wgrad(dy, x, gout, fresh, Tpad)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        dy.record_stream(side)
-        x.record_stream(side)
-        return ev
-
-    def _join_wgrad(self, ev=None):
-        """Make the current stream wait for one side-stream weight gradient (ev) or for all of them (ev=None)."""
-        if self._wg_stream is None:
-            return
-        main = torch.cuda.current_stream(self._wg_stream.device)
-        if ev is not None:
-            main.wait_event(ev)
-        else:
-            main.wait_stream(self._wg_stream)
 
     def _untouched(self, names, fresh):
         """A trainable bucket this backward does not reach: zero it on the first micro-step (the arena may hold the previous
@@ -579,35 +546,28 @@ class HipEngine:
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
         dgu = O.gemm_swiglu_bwd(dy, W.wd, gu)  # dact = dy Wd never leaves the kernel: SwiGLU backward in the epilogue
-        ev_d = ev_o = None
         if train:
-            ev_d = self._wgrad_side(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
+            self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
         del act
         dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
         if train:
-            self._wgrad_side(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
+            self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
         del dgu, gu
-        if ev_d is not None:
-            self._join_wgrad(ev_d)  # the next kernel overwrites dy in place
         dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
                             dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
         do = O.gemm_nt(dx2, W.wo, b_t=True)
         if train:
-            ev_o = self._wgrad_side(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
+            self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:],
                     rope=self.rope)  # inverse RoPE of dq, dk fused into the kernels' epilogues
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
-            self._wgrad_side(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
-        if ev_o is not None:
-            self._join_wgrad(ev_o)  # dx2 is overwritten in place next
+            self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
         dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
                            dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
         if train:
-            if self.on_grads_ready is not None:
-                self._join_wgrad()  # the bucket's all-reduce may start only when its weight gradients are complete
             self._ready(W.names)
         return dx
 
@@ -868,7 +828,6 @@ class HipEngine:
                 dead = n.startswith(VT + "post_layernorm") or any(n.startswith(VT + f"encoder.layers.{i}.") for i in range(L, tower.config.num_hidden_layers))
                 if dead or not tower_train:
                     A.gview(n).zero_()
-        self._join_wgrad()  # side-stream weight gradients complete before anything downstream (clip, optimizer) reads them
         self._ready(None)  # end of backward
 
     # ------------------------------------------------------------------------------------------

@@ -6,6 +6,8 @@ arithmetic happens here, and there is no fallback: without libmerlin_hip.so thes
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -191,14 +193,46 @@ def attn_decode(q, kcache, vcache, lens, H, D, out=None, split_kv=True):
 _splitk_ws = {}
 
 
-def wgrad_tn(dy, x, out, accum):
-    """out[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in]: both operands K-strided as they lie in memory, any T (the
-    kernel reads rows >= T of the last K-tile as zeros), split-K when the output has too few tiles to fill the chip."""
+_tail_plans = {}
+
+
+def _tail_plan(M, N, T):
+    """256 x 256 output tiles on 256 CUs run in rounds; a weight gradient whose tile count is not a multiple of 256 leaves the
+    last round partly empty (gate|up: 86 x 16 = 1376 tiles = 5.375 rounds -> 6; down: 16 x 43 = 688 = 2.69 -> 3: 10-12 % of
+    GEMMs that contract over all 32 768 tokens).  Plan: cut the output into a part that fills whole rounds and a remainder that
+    is split along K (tokens) so that ITS blocks fill whole, proportionally shorter rounds.  Returns None or
+    (axis 'm' | 'n', cut in elements, splits of the remainder)."""
+    key = (M, N, T)
+    if key in _tail_plans:
+        return _tail_plans[key]
+    if os.environ.get("MH_NO_TAIL_PLAN"):  # A/B switch for kernel development
+        return None
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    tiles, nk = tm * tn, (T + 63) // 64
+    plan = None
+    if tiles >= 256 and nk >= 128 and M % 256 == 0 and N % 256 == 0:
+        best = -(-tiles // 256) * 0.96  # must beat the plain launch by > 4 % (the reduce pass and a second launch are not free)
+        for axis, ta, tb in (("m", tm, tn), ("n", tn, tm)):
+            for a in range(ta - 1, 0, -1):
+                ca = -(-(a * tb) // 256)
+                if ca * 256 - a * tb > 0.03 * a * tb:
+                    continue
+                rem = (ta - a) * tb
+                for sp in range(2, 17):
+                    if nk // sp < 16:
+                        break
+                    # remainder rounds are 1/sp long; its fp32 partials (sp x rem tiles) are written and read once at ~5 TB/s,
+                    # expressed in rounds (one full-K round of 256 tiles takes ~T x 25.7 ns at the kernel's rate)
+                    cost = ca + -(-(rem * sp) // 256) / sp + 0.02 + sp * rem * 524288 / 5e12 / (T * 25.7e-9)
+                    if cost < best:
+                        best, plan = cost, (axis, a * 256, sp)
+    _tail_plans[key] = plan
+    return plan
+
+
+def _wgrad_call(dy, x, out, accum, splits):
     T, M = dy.shape
-    T2, N = x.shape
-    assert T == T2 and dy.dtype == x.dtype and M % 8 == 0 and N % 8 == 0
-    lda, ldb, ldc = _rowmajor(dy), _rowmajor(x), _rowmajor(out)
-    splits = int(L.lib().mh_gemm_splitk_max(i32(M), i32(N), i32(T)))
+    N = x.shape[1]
     ws = None
     if splits > 1:
         key = (dy.device, splits * M * N)
@@ -207,10 +241,30 @@ def wgrad_tn(dy, x, out, accum):
             if len(_splitk_ws) > 8:
                 _splitk_ws.clear()
             ws = _splitk_ws[key] = torch.empty(splits * M * N, dtype=torch.float32, device=dy.device)
+    L.check(L.lib().mh_gemm_splitk(p(dy), i64(_rowmajor(dy)), i32(1), p(x), i64(_rowmajor(x)), i32(1), p(out), i64(_rowmajor(out)), i32(M), i32(N),
+                                   i32(T), i32(dt_of(dy)), i32(int(accum)), i32(int(out.dtype == torch.float32)), i32(splits), p(ws),
+                                   _stream()), "mh_gemm_splitk")
+
+
+def wgrad_tn(dy, x, out, accum):
+    """out[N_out, K_in] (+)= dy[T, N_out]^T @ x[T, K_in]: both operands K-strided as they lie in memory, any T (the
+    kernel reads rows >= T of the last K-tile as zeros), split-K when the output has too few tiles to fill the chip, and a
+    two-part launch (full rounds + a K-split remainder, see _tail_plan) when its tile count leaves a partly empty last round."""
+    T, M = dy.shape
+    T2, N = x.shape
+    assert T == T2 and dy.dtype == x.dtype and M % 8 == 0 and N % 8 == 0
     with _timed("gemm_nt", 2.0 * M * N * T):
-        L.check(L.lib().mh_gemm_splitk(p(dy), i64(lda), i32(1), p(x), i64(ldb), i32(1), p(out), i64(ldc), i32(M), i32(N), i32(T),
-                                       i32(dt_of(dy)), i32(int(accum)), i32(int(out.dtype == torch.float32)), i32(splits), p(ws),
-                                       _stream()), "mh_gemm_splitk")
+        plan = _tail_plan(M, N, T)
+        if plan is None:
+            _wgrad_call(dy, x, out, accum, int(L.lib().mh_gemm_splitk_max(i32(M), i32(N), i32(T))))
+        else:
+            axis, cut, sp = plan
+            if axis == "m":
+                _wgrad_call(dy[:, :cut], x, out[:cut], accum, 1)
+                _wgrad_call(dy[:, cut:], x, out[cut:], accum, sp)
+            else:
+                _wgrad_call(dy, x[:, :cut], out[:, :cut], accum, 1)
+                _wgrad_call(dy, x[:, cut:], out[:, cut:], accum, sp)
     return out
 
 

@@ -243,7 +243,7 @@ def main():
     # (PMC collection cannot run inside the timed process); the committed summary is read back here.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")) as f:
             traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e9, 3) if args.config == "cfg3" and not args.fwd_only and not args.fp8_train else None
     except Exception:
         traffic = None
@@ -261,7 +261,7 @@ def main():
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "gemm_nt_256/gemm_nt_128 (bf16 MFMA GEMM, all launches)"),
                      "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r01_gemm_traffic.json)", "launches": n,
+                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r02_gemm_traffic.json)", "launches": n,
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
     }
     if fwd_ms is not None:

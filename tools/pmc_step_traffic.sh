@@ -8,7 +8,7 @@ i=0
 for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum"; do
   i=$((i+1))
   rm -rf /tmp/pmcs$i
-  timeout 600 rocprofv3 --pmc $set -d /tmp/pmcs$i -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pmcs$i.log 2>&1 || echo "pass $i failed (counter set: $set)"
+  timeout 600 rocprofv3 --pmc $set -d /tmp/pmcs$i -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-leg > /tmp/pmcs$i.log 2>&1 || echo "pass $i failed (counter set: $set)"
 done
 python $R/tools/pmc_step_traffic.py /tmp/pmcs1 /tmp/pmcs2 /tmp/pmcs3 > $R/gpurun_out/$OUT
 cat $R/gpurun_out/$OUT

@@ -70,6 +70,10 @@ def generate(model, input_ids, images=None, attention_mask=None, max_new_tokens=
              pad_token_id=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0, num_beams=1, length_penalty=1.0,
              early_stopping=False, stopping_criteria=None, use_cache=True, use_graph=True, fp8_weights=False, seed=None,
              **unused):
+    for k, default in (("repetition_penalty", 1.0), ("no_repeat_ngram_size", 0), ("num_return_sequences", 1), ("num_beam_groups", 1),
+                       ("penalty_alpha", None), ("typical_p", 1.0), ("min_new_tokens", None), ("bad_words_ids", None)):
+        if unused.get(k, default) not in (default, None):
+            raise NotImplementedError(f"generate({k}=...) is not part of the decoding modes the reference's eval scripts use")
     cfg = model.config
     eos_ids = _as_list(cfg.eos_token_id if eos_token_id is None else eos_token_id)
     pad = pad_token_id if pad_token_id is not None else (cfg.pad_token_id if cfg.pad_token_id is not None else (eos_ids[0] if eos_ids else 0))

@@ -627,7 +627,9 @@ class HipEngine:
         if self.strict_checks:
             if input_ids is not None or labels is not None or mask is not None:
                 O.check_inputs(input_ids, labels, mask, lens, err_dev, m.config.vocab_size)
-            host = torch.empty(10, dtype=torch.int32, pin_memory=True)
+            if getattr(self, "_err_host", None) is None:
+                self._err_host = torch.empty(10, dtype=torch.int32, pin_memory=True)  # reused: every forward consumes its own check
+            host = self._err_host
             host.copy_(err_dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()

@@ -282,7 +282,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
 
     # ---- construction helpers ----------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, config=None, cache_dir=None, torch_dtype=None, **kw):
+    def from_pretrained(cls, path, config=None, cache_dir=None, torch_dtype=None, dtype=None, **kw):
         """builder.py:70-74.  Loads config.json and, when present, weights in the reference layout."""
         from ..checkpoint import iter_checkpoint
 
@@ -292,6 +292,7 @@ class MMGPTLlamaForCausalLM(nn.Module):
         for k, v in iter_checkpoint(path, lambda k: k in own) if os.path.isdir(path) else ():
             with torch.no_grad():
                 own[k].copy_(v)
+        torch_dtype = dtype if dtype is not None else torch_dtype  # (transformers >= 5 spells it `dtype`)
         if torch_dtype is not None:
             model.to(dtype=torch_dtype)
         return model

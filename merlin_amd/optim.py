@@ -77,16 +77,18 @@ class FusedAdamW:
             self.v = torch.zeros(A.total, dtype=torch.float32, device=A.flat.device)
         hp = per_param_hparams(A.params.items(), 1.0, self.weight_decay, self.lr_scale_fn)  # lr as a multiplier of self.lr
         runs = []
-        for n in A.names:
+        prev = -2  # index (arena order) of the last trainable parameter: runs only merge DIRECTLY adjacent parameters
+        for idx, n in enumerate(A.names):
             p = A.params[n]
             if not p.requires_grad:
                 continue
             sc, wd = hp[n]
             off, num = A.offset[n], p.numel()
-            if runs and runs[-1][2] == sc and runs[-1][3] == wd and runs[-1][0] + runs[-1][1] <= off and off - (runs[-1][0] + runs[-1][1]) < 256:
-                runs[-1][1] = off + num - runs[-1][0]  # merge (alignment gaps hold zeros and stay zero)
+            if runs and prev == idx - 1 and runs[-1][2] == sc and runs[-1][3] == wd:
+                runs[-1][1] = off + num - runs[-1][0]  # merge (alignment gaps between neighbours hold zeros and stay zero)
             else:
                 runs.append([off, num, sc, wd])
+            prev = idx
         self._runs = runs
         self._flat_id = sig
         return A

@@ -119,6 +119,11 @@ int mh_quant_fp8_rows_t(const void* x, int64_t ldx, void* qt, int64_t ldq, float
  * with max_i s[i]), which mh_quant_fp8_rows already produced: no column-maximum pass over the data. */
 int mh_quant_fp8_t_scaled(const void* x, int64_t ldx, void* qt, int64_t ldq, const float* scales, int R, int C, int dt, void* stream);
 int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream);
+/* Both operand forms of a gradient tensor from TWO reads of it (row + column maxima by order-independent atomicMax in one pass over
+ * 128 x 128 tiles, then the row-quantised copy q [R, ldq] / sr [R] and the transposed column-quantised copy qt [C, ldqt] / sc [C]
+ * from one more): dgrad consumes (q, sr), wgrad (qt, sc).  ws: R + C uints of scratch (zeroed here). */
+int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc, unsigned* ws,
+                            int R, int C, int dt, void* stream);
 int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* gu,
                            int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);

@@ -78,6 +78,110 @@ __global__ __launch_bounds__(256) void quant_fp8_transposed_k(const uint16_t* __
   }
 }
 
+// ---- row AND column maxima of x [R, C] in ONE read: 128 x 128 tiles, fp32-bit atomicMax (non-negative floats order like uints;
+// max is order-independent, so the result is deterministic) --------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void absmax_rc_k(const uint16_t* __restrict__ x, int64_t ldx, unsigned* __restrict__ rmax, unsigned* __restrict__ cmax,
+                                                   int R, int C) {
+  __shared__ float colred[16][128];
+  const int c0 = blockIdx.x * 128, r0 = blockIdx.y * 128;
+  const int cg = threadIdx.x & 15, rq = threadIdx.x >> 4;  // 16 column groups of 8, 16 row groups of 8 rows
+  const int col = c0 + cg * 8;
+  float cm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + rq * 8 + i;
+    float rm = 0.f;
+    if (r < R && col < C) {
+      float f[8];
+      unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + col), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = fabsf(f[j]);
+        rm = fmaxf(rm, a);
+        cm[j] = fmaxf(cm[j], a);
+      }
+    }
+    // row maximum over the tile's 128 columns: the 16 lanes cg = 0..15 of one rq are consecutive lanes
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) rm = fmaxf(rm, __shfl_xor(rm, o, 64));
+    if (cg == 0 && r < R && rm > 0.f) atomicMax(rmax + r, __float_as_uint(rm));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) colred[rq][cg * 8 + j] = cm[j];
+  __syncthreads();
+  if (threadIdx.x < 128 && c0 + threadIdx.x < C) {
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m = fmaxf(m, colred[q][threadIdx.x]);
+    if (m > 0.f) atomicMax(cmax + c0 + threadIdx.x, __float_as_uint(m));
+  }
+}
+
+// One read of a 128 x 128 tile -> its row-quantised bytes q[r, c] (scale sr[r]) AND its transposed column-quantised bytes
+// qt[c, r] (scale sc[c]); both written as 128-byte row segments.
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_both_k(const uint16_t* __restrict__ x, int64_t ldx, const unsigned* __restrict__ rmax,
+                                                        const unsigned* __restrict__ cmax, uint8_t* __restrict__ q, int64_t ldq,
+                                                        float* __restrict__ sr, uint8_t* __restrict__ qt, int64_t ldqt, float* __restrict__ sc,
+                                                        int R, int C) {
+  __shared__ unsigned tile[128][33];  // [column][32 row-quads]
+  const int c0 = blockIdx.x * 128, r0 = blockIdx.y * 128;
+  const int cg = threadIdx.x & 15, rq = threadIdx.x >> 4;
+  const int col = c0 + cg * 8;
+  float cinv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float m = (col + j < C) ? __uint_as_float(cmax[col + j]) : 0.f;
+    const float s = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+    cinv[j] = 1.0f / s;
+    if (blockIdx.y == 0 && rq == 0 && col + j < C) sc[col + j] = s;
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float v[4][8];
+    const int rb = r0 + pass * 64 + rq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + i;
+      if (r < R && col < C) {
+        unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + col), v[i]);
+        const float m = __uint_as_float(rmax[r]);
+        const float s = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / s;
+        if (blockIdx.x == 0 && cg == 0) sr[r] = s;
+        int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, p0, true);
+        int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, 0, false);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, p1, true);
+        *(uint2*)(q + (int64_t)r * ldq + col) = make_uint2((unsigned)p0, (unsigned)p1);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0][j] * cinv[j], v[1][j] * cinv[j], 0, false);
+      p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2][j] * cinv[j], v[3][j] * cinv[j], p, true);
+      tile[cg * 8 + j][pass * 16 + rq] = (unsigned)p;
+    }
+  }
+  __syncthreads();
+  // 128 output rows (columns of x) x 128 B: thread -> (row = t >> 1, 64-byte half = t & 1)
+  const int orow = threadIdx.x >> 1, hf = threadIdx.x & 1;
+  if (c0 + orow < C) {
+    uint4* dst = (uint4*)(qt + (int64_t)(c0 + orow) * ldqt + r0 + hf * 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint4 a;
+      a.x = tile[orow][hf * 16 + 4 * k + 0]; a.y = tile[orow][hf * 16 + 4 * k + 1];
+      a.z = tile[orow][hf * 16 + 4 * k + 2]; a.w = tile[orow][hf * 16 + 4 * k + 3];
+      dst[k] = a;
+    }
+  }
+}
+
 // out[0..m) = max(1e-30.., max_i s[i]): the tensor-wide scale of a row-quantised tensor = the largest of its row scales
 __global__ __launch_bounds__(1024) void max_to_vec_k(const float* __restrict__ s, int n, float* __restrict__ out, int m) {
   __shared__ float red[16];
@@ -107,6 +211,31 @@ extern "C" int mh_quant_fp8_t_scaled(const void* x, int64_t ldx, void* qt, int64
   else if (dt == MH_F16)
     hipLaunchKernelGGL(quant_fp8_transposed_k<MH_F16>, g2, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, scales, (uint8_t*)qt, ldq, R, C);
   else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+// x [R, C] -> (q [R, ldq] row-quantised, sr [R]) and (qt [C, ldqt >= round_up(R, 128)] column-quantised + transposed, sc [C]) with two
+// reads of x (maxima, then both copies) instead of four; ws: R + C uints of scratch.
+extern "C" int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc,
+                                       unsigned* ws, int R, int C, int dt, void* stream) {
+  if (!x || !q || !sr || !qt || !sc || !ws || R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldq & 7) || (ldqt & 15) || !aligned16(x) || !aligned16(qt) ||
+      (((uintptr_t)q) & 7u))
+    return MH_ERR_ARG;
+  if (ldqt < (int64_t)(R + 127) / 128 * 128 || ldq < C) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)(R + C) * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((C + 127) / 128, (R + 127) / 128);
+  unsigned *rmax = ws, *cmax = ws + R;
+  if (dt == MH_BF16) {
+    hipLaunchKernelGGL(absmax_rc_k<MH_BF16>, grid, dim3(256), 0, st, (const uint16_t*)x, ldx, rmax, cmax, R, C);
+    hipLaunchKernelGGL(quant_fp8_both_k<MH_BF16>, grid, dim3(256), 0, st, (const uint16_t*)x, ldx, (const unsigned*)rmax, (const unsigned*)cmax, (uint8_t*)q, ldq, sr,
+                       (uint8_t*)qt, ldqt, sc, R, C);
+  } else {
+    hipLaunchKernelGGL(absmax_rc_k<MH_F16>, grid, dim3(256), 0, st, (const uint16_t*)x, ldx, rmax, cmax, R, C);
+    hipLaunchKernelGGL(quant_fp8_both_k<MH_F16>, grid, dim3(256), 0, st, (const uint16_t*)x, ldx, (const unsigned*)rmax, (const unsigned*)cmax, (uint8_t*)q, ldq, sr,
+                       (uint8_t*)qt, ldqt, sc, R, C);
+  }
   MH_LAUNCH_CHECK();
 }
 extern "C" int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream) {

@@ -481,13 +481,14 @@ class HipEngine:
         # the row scales (one float per token) are kept: their maximum is the tensor-wide scale of the transposed wgrad operand
         return y, ((h1, qkv, o, lse, x2, h2, gu, act, (a1[1], a2[1], a3[1], a4[1])) if keep else None)
 
-    def _wgrad_fp8(self, dy, sdy, x, sx, gout, fresh):
+    def _wgrad_fp8(self, dyT8, x, sx, gout, fresh):
         """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as transposed e4m3 copies (contraction over the
         tokens, zero-padded to a multiple of 128).  The GRADIENT operand is scaled per output feature (column maxima: a pass
         over dy - the q / k / v thirds of dqkv differ by orders of magnitude, a tensor-wide scale flushes the small ones to
-        zero, measured); the ACTIVATION operand (norm outputs, attention output, SwiGLU output: homogeneous columns) by its
+        zero, measured - shared with the row quantisation of the same tensor for the dgrad: O.quant_fp8_both reads it twice in
+        all); the ACTIVATION operand (norm outputs, attention output, SwiGLU output: homogeneous columns) by its
         tensor-wide scale = the largest of the row scales its forward quantisation already produced (single pass)."""
-        O.gemm_fp8(O.quant_fp8_rows_t(dy), O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
+        O.gemm_fp8(dyT8, O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
 
     def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
@@ -502,30 +503,30 @@ class HipEngine:
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
         dt = x.dtype
-        dy8 = O.quant_fp8_rows(dy)
+        dy8, dyT8 = O.quant_fp8_both(dy) if train else (O.quant_fp8_rows(dy), None)
         dgu = O.gemm_fp8_swiglu_bwd(dy8, Q["wdT"], gu)  # SwiGLU backward in the dgrad's store phase
         if train:
-            self._wgrad_fp8(dy, dy8[1], act, s_act, A.gview(p + "mlp.down_proj.weight"), fresh)
-        del act, gu, dy8
-        dgu8 = O.quant_fp8_rows(dgu)
+            self._wgrad_fp8(dyT8, act, s_act, A.gview(p + "mlp.down_proj.weight"), fresh)
+        del act, gu, dy8, dyT8
+        dgu8, dguT8 = O.quant_fp8_both(dgu) if train else (O.quant_fp8_rows(dgu), None)
         dh2 = O.gemm_fp8(dgu8, Q["wguT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dgu, dgu8[1], h2, s_h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)
-        del dgu, dgu8
+            self._wgrad_fp8(dguT8, h2, s_h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)
+        del dgu, dgu8, dguT8
         dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
                             dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
-        dx28 = O.quant_fp8_rows(dx2)
+        dx28, dx2T8 = O.quant_fp8_both(dx2) if train else (O.quant_fp8_rows(dx2), None)
         do = O.gemm_fp8(dx28, Q["woT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dx2, dx28[1], o, s_o, A.gview(p + "self_attn.o_proj.weight"), fresh)
-        del dx28
+            self._wgrad_fp8(dx2T8, o, s_o, A.gview(p + "self_attn.o_proj.weight"), fresh)
+        del dx28, dx2T8
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:], rope=self.rope)
-        dqkv8 = O.quant_fp8_rows(dqkv)
+        dqkv8, dqkvT8 = O.quant_fp8_both(dqkv) if train else (O.quant_fp8_rows(dqkv), None)
         dh1 = O.gemm_fp8(dqkv8, Q["wqkvT"], out_dtype=dt)
         if train:
-            self._wgrad_fp8(dqkv, dqkv8[1], h1, s_h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh)
+            self._wgrad_fp8(dqkvT8, h1, s_h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh)
         dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
                            dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
         if train:

@@ -332,6 +332,28 @@ def quant_fp8_rows_t(x):
     return qt, sc
 
 
+_both_ws = {}
+
+
+def quant_fp8_both(x):
+    """x [R, C] (16-bit) -> ((q [R, C], s_row [R]), (qt [C, round_up(R, 128)], s_col [C])): the row-quantised operand (dgrad) and the
+    transposed, per-feature-scaled operand (wgrad) of a gradient tensor from two reads of it."""
+    R, C_ = x.shape
+    Rp = round_up(R, 128)
+    q = torch.empty(R, C_, dtype=torch.uint8, device=x.device)
+    sr = torch.empty(R, dtype=torch.float32, device=x.device)
+    qt = torch.empty(C_, Rp, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(C_, dtype=torch.float32, device=x.device)
+    ws = _both_ws.get((x.device, R + C_))
+    if ws is None:
+        if len(_both_ws) > 16:
+            _both_ws.clear()
+        ws = _both_ws[(x.device, R + C_)] = torch.empty(R + C_, dtype=torch.int32, device=x.device)
+    L.check(L.lib().mh_quant_fp8_rows_and_t(p(x), i64(_rowmajor(x)), p(q), i64(C_), p(sr), p(qt), i64(Rp), p(sc), p(ws), i32(R), i32(C_),
+                                            i32(dt_of(x)), _stream()), "mh_quant_fp8_rows_and_t")
+    return (q, sr), (qt, sc)
+
+
 def quant_fp8_t_from_rows(x, row_scales):
     """x [R, C] (16-bit) -> (qt uint8 [C, round_up(R, 128)], s fp32 [C] = one tensor-wide scale, the largest of x's row scales
     as produced by quant_fp8_rows): the transposed operand of the wgrad GEMMs in ONE pass over x."""

@@ -42,6 +42,24 @@ def test_transposed_row_quantisation(dtype, R, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,C", [(256, 128), (1000, 520), (29, 256), (4096, 11008), (32768, 4096)])
+def test_fused_row_and_transposed_quantisation(dtype, R, C):
+    """The two-read form used for gradient tensors must give exactly the bytes and scales of the separate kernels."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(R * 3 + C)
+    x = (torch.randn(R, C, generator=g, device="cuda") * torch.rand(1, C, generator=g, device="cuda") * 3).to(dtype)
+    x[:, 5] = 0
+    if R > 7:
+        x[7] = 0
+    (q, sr), (qt, sc) = O.quant_fp8_both(x)
+    q1, sr1 = O.quant_fp8_rows(x)
+    qt1, sc1 = O.quant_fp8_rows_t(x)
+    assert torch.equal(sr, sr1) and torch.equal(q, q1)
+    assert torch.equal(sc, sc1) and torch.equal(qt, qt1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("R,C", [(300, 256), (4096, 1024)])
 def test_transposed_quantisation_with_tensor_scale(dtype, R, C):
     """The single-pass form of the training step: one scale for the whole tensor = the largest row scale of its row-quantised twin."""

@@ -142,6 +142,9 @@ int mh_transpose16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, i
 /* ---- norms -------------------------------------------------------------------------- */
 /* LlamaRMSNorm (transformers modeling_llama.py LlamaRMSNorm; called 65x per forward). */
 int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_or_null, int rows, int d, float eps, int dt, void* stream);
+/* RMSNorm forward + the row-quantised e4m3 copy (q [rows, d] bytes, scales [rows]) of its output in the same launch: bit-identical
+ * to mh_rmsnorm_fwd followed by mh_quant_fp8_rows (fp8 training / inference paths). */
+int mh_rmsnorm_fwd_q8(const void* x, const void* w, void* y, void* q, float* scales, int rows, int d, float eps, int dt, void* stream);
 /* dx (and fp32 partial dw[nblk, d], nblk = mh_norm_bwd_partials(rows)) */
 int mh_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
 /* nn.LayerNorm (CLIP pre_layrnorm / layer_norm1 / layer_norm2, eps 1e-5). */

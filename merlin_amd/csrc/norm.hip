@@ -45,6 +45,60 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_k(const uint16_t* __restrict_
   }
 }
 
+// RMSNorm forward that also emits the row-quantised e4m3 copy of its (16-bit rounded) output + the row scale: the operand of the
+// fp8 GEMM that follows, without a separate pass over y (BASELINE cfg 5: quantisation fused into the norm).  Bit-identical to
+// rmsnorm_fwd_k followed by quant_fp8_rows_k.  x and w are re-read from L1/L2 (a row is 8 KB), y and q are written once.
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_q8_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
+                                                        uint8_t* __restrict__ q, float* __restrict__ sc, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const uint4* xr = (const uint4*)(x + (int64_t)row * d);
+  const uint4* wr = (const uint4*)w;
+  uint4* yr = (uint4*)(y + (int64_t)row * d);
+  const int nch = d >> 3;
+  float ss = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(xr[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)d + eps);
+  float mx = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8], g[8];
+    unpack8<DT>(xr[c], f);
+    unpack8<DT>(wr[c], g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+    const uint4 pk = pack8<DT>(f);
+    yr[c] = pk;
+    unpack8<DT>(pk, f);  // the ROUNDED values are what the stand-alone quantiser sees
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+  }
+  mx = wave_max(mx);
+  const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) sc[row] = s;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8], g[8];
+    unpack8<DT>(xr[c], f);
+    unpack8<DT>(wr[c], g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+    unpack8<DT>(pack8<DT>(f), f);
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
+    *(uint2*)(q + (int64_t)row * d + c * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                        const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
@@ -318,6 +372,17 @@ extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
   else return MH_ERR_DTYPE;
   MH_LAUNCH_CHECK();
 }
+extern "C" int mh_rmsnorm_fwd_q8(const void* x, const void* w, void* y, void* q, float* scales, int rows, int d, float eps, int dt, void* stream) {
+  if (!x || !w || !y || !q || !scales || rows <= 0 || d <= 0 || (d & 7) || !aligned16(x) || !aligned16(w) || !aligned16(y) || (((uintptr_t)q) & 7u)) return MH_ERR_ARG;
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(rmsnorm_fwd_q8_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (uint8_t*)q, scales, rows, d, eps);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(rmsnorm_fwd_q8_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (uint8_t*)q, scales, rows, d, eps);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+
 
 extern "C" int mh_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps,
                                 int dt, void* stream) {

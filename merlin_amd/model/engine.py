@@ -433,16 +433,16 @@ class HipEngine:
         cfg = self.model.config
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         eps = cfg.rms_norm_eps
-        h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-        qkv = O.gemm_fp8_rope(O.quant_fp8_rows(h1), Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
+        _, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)
+        qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         if kv_out is not None:
             kv_out[0][:, :S].copy_(k.view(B, S, d))
             kv_out[1][:, :S].copy_(v.view(B, S, d))
         o, _ = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
-        h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-        _, act = O.gemm_fp8_swiglu_fwd(O.quant_fp8_rows(h2), Q["wgu"], out_dtype=x.dtype)
+        _, a3 = O.rmsnorm_fwd_q8(x2, W.ln2, eps)
+        _, act = O.gemm_fp8_swiglu_fwd(a3, Q["wgu"], out_dtype=x.dtype)
         return O.gemm_fp8(O.quant_fp8_rows(act), Q["wd"], out_dtype=x.dtype, resid=x2)
 
     # ---- fp8 TRAINING step (BASELINE cfg 5: "fp8 MFMA weight path"; no reference counterpart) -------------
@@ -466,15 +466,13 @@ class HipEngine:
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         eps = cfg.rms_norm_eps
         Q = self.fp8_train_weights(li)
-        h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-        a1 = O.quant_fp8_rows(h1)
+        h1, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)  # norm + row quantisation of its output in one launch
         qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
         a2 = O.quant_fp8_rows(o)
         x2 = O.gemm_fp8(a2, Q["wo"], out_dtype=x.dtype, resid=x)
-        h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-        a3 = O.quant_fp8_rows(h2)
+        h2, a3 = O.rmsnorm_fwd_q8(x2, W.ln2, eps)
         gu, act = O.gemm_fp8_swiglu_fwd(a3, Q["wgu"], out_dtype=x.dtype)
         a4 = O.quant_fp8_rows(act)
         y = O.gemm_fp8(a4, Q["wd"], out_dtype=x.dtype, resid=x2)

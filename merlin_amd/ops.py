@@ -448,6 +448,17 @@ def rmsnorm_fwd(x, w, eps, out=None):
     return out
 
 
+def rmsnorm_fwd_q8(x, w, eps):
+    """-> (y, (q uint8 [rows, d], scales fp32 [rows])): RMSNorm + row-quantised e4m3 copy of its output in one launch."""
+    rows, d = x.shape
+    assert x.is_contiguous() and w.is_contiguous()
+    y = torch.empty_like(x)
+    q = torch.empty(rows, d, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mh_rmsnorm_fwd_q8(p(x), p(w), p(y), p(q), p(sc), i32(rows), i32(d), f32(eps), i32(dt_of(x)), _stream()), "mh_rmsnorm_fwd_q8")
+    return y, (q, sc)
+
+
 def norm_partials(rows: int) -> int:
     return int(L.lib().mh_norm_bwd_partials(i32(rows)))
 

@@ -106,6 +106,20 @@ def test_fp8_dgrad_and_wgrad_products(dtype, T, No, Ki):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,d", [(613, 4096), (37, 256), (1000, 1024)])
+def test_rmsnorm_with_fused_row_quantisation_is_bit_identical(dtype, rows, d):
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, d, generator=g, device="cuda").to(dtype)
+    w = (1 + 0.1 * torch.randn(d, generator=g, device="cuda")).to(dtype)
+    y, (q, s) = O.rmsnorm_fwd_q8(x, w, 1e-6)
+    y0 = O.rmsnorm_fwd(x, w, 1e-6)
+    q0, s0 = O.quant_fp8_rows(y0)
+    assert torch.equal(y, y0) and torch.equal(s, s0) and torch.equal(q, q0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_swiglu_backward_fused_matches_unfused(dtype):
     from merlin_amd import ops as O
 

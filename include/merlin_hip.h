@@ -98,13 +98,21 @@ int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, int64_t ldw
  * usual epilogue) in `dt_out`.  mh_quant_fp8_rows produces (q, scales) from a 16-bit matrix: scale = max|row| / 448.
  * K % 128 == 0; lda, ldb in bytes, % 16 == 0. */
 int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scales, int R, int K, int dt, void* stream);
-int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C, int64_t ldc,
-                const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out, int epilogue, void* stream);
+int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
+                int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out, int epilogue, void* stream);
 /* fp8 forms of mh_gemm_nt_rope and mh_gemm_swiglu_fwd (the same fused store phases behind the fp8 product). */
-int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C, int64_t ldc,
-                     int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols, void* stream);
-int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* gu,
-                           int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out, void* stream);
+int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
+                     int64_t ldc, int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols, void* stream);
+int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp,
+                           void* gu, int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out, void* stream);
+/* b_exp (nullable, all four fp8 GEMM entry points): per-128-block scales of the B operand (the weights) - BASELINE cfg 5's
+ * "per-128-block scales" - as 4-bit exponents e, block scale = sb[n] * 2^-e, applied by the MFMA's own E8M0 block-scale operand
+ * (v_mfma_scale_f32_16x16x128_f8f6f4) at no cost in the K loop.  Layout produced by mh_quant_fp8_rows_e4 / mh_quant_fp8_rows_t_e4:
+ * [ceil(N / 256) * 2 groups of 128 rows][G bytes], G = round_up(K / 128 * 64, 4096), a group = [K / 128 blocks][64 B], two rows per
+ * byte (low nibble = even row).  K <= 24 576. */
+int mh_quant_fp8_rows_e4(const void* w, int64_t ldw, void* q, float* scales, void* exps, int N, int K, int dt, void* stream);
+int mh_quant_fp8_rows_t_e4(const void* w, int64_t ldw, void* qt, int64_t ldq, float* scales, void* exps, unsigned* amax_ws, int R, int C, int dt,
+                           void* stream);
 /* ---- fp8 TRAINING step (BASELINE cfg 5: fp8 MFMA weight path).  Every GEMM is an NT product of two row-quantised operands:
  *   forward  y  = x W^T        rowquant(x)    [T, K]   x rowquant(W)     [N, K]
  *   dgrad    dx = dy W         rowquant(dy)   [T, N]   x rowquant(W^T)   [K, N]
@@ -124,8 +132,8 @@ int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream);
  * from one more): dgrad consumes (q, sr), wgrad (qt, sc).  ws: R + C uints of scratch (zeroed here). */
 int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc, unsigned* ws,
                             int R, int C, int dt, void* stream);
-int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* gu,
-                           int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
+int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* wt_exp,
+                           const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,

@@ -78,6 +78,139 @@ __global__ __launch_bounds__(256) void quant_fp8_transposed_k(const uint16_t* __
   }
 }
 
+// ---- weights: per-row fp32 scale + per-(row, 128-k block) 4-bit exponent e (block scale = s[n] * 2^-e), the form the fp8 GEMM applies
+// through the MFMA's E8M0 block-scale operand (BASELINE cfg 5: "per-128-block scales").  e = floor(log2(rowmax / blockmax)) in [0, 15]:
+// every block is scaled up by the largest power of two that keeps it inside the row's range, so small blocks keep e4m3's full
+// 3-bit mantissa instead of sinking towards the subnormals.  Exponent image: [row / 128][G][...] as documented in merlin_hip.h.
+__device__ __forceinline__ int block_exp(float rowmax, float bmax) {
+  if (!(bmax > 0.f)) return 15;
+  int ea, eb;
+  const float ma = frexpf(rowmax, &ea), mb = frexpf(bmax, &eb);
+  const int e = ea - eb - (ma < mb ? 1 : 0);  // exact floor(log2(rowmax / bmax))
+  return min(15, max(0, e));
+}
+
+// one wave per PAIR of rows (2p, 2p + 1): the two rows share every exponent byte
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_rows_e4_k(const uint16_t* __restrict__ w, int64_t ldw, uint8_t* __restrict__ q, float* __restrict__ sc,
+                                                           uint8_t* __restrict__ ex, int64_t G, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (n0 >= N) return;
+  const bool two = n0 + 1 < N;
+  const uint4* r0 = (const uint4*)(w + (int64_t)n0 * ldw);
+  const uint4* r1 = (const uint4*)(w + (int64_t)(two ? n0 + 1 : n0) * ldw);
+  const int nch = K >> 3;  // K % 128 == 0: 16 chunks per block
+  float m0 = 0.f, m1 = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float f[8];
+    unpack8<DT>(r0[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m0 = fmaxf(m0, fabsf(f[i]));
+    unpack8<DT>(r1[c], f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m1 = fmaxf(m1, fabsf(f[i]));
+  }
+  m0 = wave_max(m0);
+  m1 = wave_max(m1);
+  const float s0 = m0 > 0.f ? m0 * (1.0f / 448.0f) : 1.0f, s1 = m1 > 0.f ? m1 * (1.0f / 448.0f) : 1.0f;
+  if (lane == 0) {
+    sc[n0] = s0;
+    if (two) sc[n0 + 1] = s1;
+  }
+  uint8_t* eb = ex + (int64_t)(n0 >> 7) * G + ((n0 & 127) >> 1);
+  for (int c = lane; c < nch; c += 64) {
+    float f0[8], f1[8];
+    unpack8<DT>(r0[c], f0);
+    unpack8<DT>(r1[c], f1);
+    float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { b0 = fmaxf(b0, fabsf(f0[i])); b1 = fmaxf(b1, fabsf(f1[i])); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { b0 = fmaxf(b0, __shfl_xor(b0, o, 64)); b1 = fmaxf(b1, __shfl_xor(b1, o, 64)); }
+    const int e0 = block_exp(m0, b0), e1 = two ? block_exp(m1, b1) : 0;
+    const float i0 = ldexpf(1.0f / s0, e0), i1 = ldexpf(1.0f / s1, e1);
+    const int kb = c >> 4;
+    if ((lane & 15) == 0) eb[(int64_t)kb * 64] = (uint8_t)(e0 | (e1 << 4));
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[0] * i0, f0[1] * i0, 0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[2] * i0, f0[3] * i0, p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[4] * i0, f0[5] * i0, 0, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[6] * i0, f0[7] * i0, p1, true);
+    *(uint2*)(q + (int64_t)n0 * K + c * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+    if (two) {
+      p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f1[0] * i1, f1[1] * i1, 0, false);
+      p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f1[2] * i1, f1[3] * i1, p0, true);
+      p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f1[4] * i1, f1[5] * i1, 0, false);
+      p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f1[6] * i1, f1[7] * i1, p1, true);
+      *(uint2*)(q + (int64_t)(n0 + 1) * K + c * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+    }
+  }
+}
+
+// transposed form (rows of the output = columns c of x, contraction along x's rows): a 64 x 128 tile holds exactly one 128-block of
+// every output row it touches, so the block maximum is a reduction inside the tile
+template <int DT>
+__global__ __launch_bounds__(256) void quant_fp8_transposed_e4_k(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ sc,
+                                                                 uint8_t* __restrict__ qt, int64_t ldq, uint8_t* __restrict__ ex, int64_t G, int R, int C) {
+  __shared__ unsigned tile[64][33];
+  __shared__ float wmax[4][64];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 128;
+  const int cg = threadIdx.x & 7, rq = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+  const int col = c0 + cg * 8;
+  float v[4][8], bm[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bm[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + rq * 4 + i;
+    if (r < R && col < C) {
+      unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + col), v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bm[j] = fmaxf(bm[j], fabsf(v[i][j]));
+  }
+  // lanes with the same cg inside a wave: lane = 8 * (rq & 7) + cg
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) bm[j] = fmaxf(bm[j], __shfl_xor(bm[j], o, 64));
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wmax[wave][cg * 8 + j] = bm[j];
+  }
+  __syncthreads();
+  unsigned ebytes = 0;
+  float inv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float b = fmaxf(fmaxf(wmax[0][cg * 8 + j], wmax[1][cg * 8 + j]), fmaxf(wmax[2][cg * 8 + j], wmax[3][cg * 8 + j]));
+    const float s = (col + j < C) ? sc[col + j] : 1.0f;
+    const int e = block_exp(s * 448.0f, b);
+    inv[j] = ldexpf(1.0f / s, e);
+    ebytes |= (unsigned)e << (4 * j);  // nibble j: columns col + j, i.e. byte j/2, low nibble = even column
+  }
+  if (rq == 0 && col < C) *(unsigned*)(ex + (int64_t)(col >> 7) * G + (int64_t)blockIdx.y * 64 + ((col & 127) >> 1)) = ebytes;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0][j] * inv[j], v[1][j] * inv[j], 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2][j] * inv[j], v[3][j] * inv[j], p, true);
+    tile[cg * 8 + j][rq] = (unsigned)p;
+  }
+  __syncthreads();
+  const int orow = threadIdx.x >> 2, seg = threadIdx.x & 3;
+  if (c0 + orow < C) {
+    uint4 a, b;
+    a.x = tile[orow][seg * 8 + 0]; a.y = tile[orow][seg * 8 + 1]; a.z = tile[orow][seg * 8 + 2]; a.w = tile[orow][seg * 8 + 3];
+    b.x = tile[orow][seg * 8 + 4]; b.y = tile[orow][seg * 8 + 5]; b.z = tile[orow][seg * 8 + 6]; b.w = tile[orow][seg * 8 + 7];
+    uint4* dst = (uint4*)(qt + (int64_t)(c0 + orow) * ldq + r0 + seg * 32);
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
 // ---- row AND column maxima of x [R, C] in ONE read: 128 x 128 tiles, fp32-bit atomicMax (non-negative floats order like uints;
 // max is order-independent, so the result is deterministic) --------------------------------------------------------------
 template <int DT>
@@ -213,6 +346,45 @@ extern "C" int mh_quant_fp8_t_scaled(const void* x, int64_t ldx, void* qt, int64
   else return MH_ERR_DTYPE;
   MH_LAUNCH_CHECK();
 }
+extern "C" int mh_quant_fp8_rows_e4(const void* w, int64_t ldw, void* q, float* scales, void* exps, int N, int K, int dt, void* stream) {
+  if (!w || !q || !scales || !exps || N <= 0 || K <= 0 || (K & 127) || (ldw & 7) || !aligned16(w) || (((uintptr_t)q) & 7u) || K > 24576) return MH_ERR_ARG;
+  const int64_t G = ((int64_t)(K / 128) * 64 + 4095) / 4096 * 4096;
+  const dim3 grid(((N + 1) / 2 + 3) / 4), block(256);
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(quant_fp8_rows_e4_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)w, ldw, (uint8_t*)q, scales, (uint8_t*)exps, G, N, K);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(quant_fp8_rows_e4_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)w, ldw, (uint8_t*)q, scales, (uint8_t*)exps, G, N, K);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+
+// w [R, C] -> qt [C, ldq >= round_up(R, 128)] = e4m3(w^T / (s[c] 2^-e[c, r / 128])), s [C], exponent image of the C output rows
+extern "C" int mh_quant_fp8_rows_t_e4(const void* x, int64_t ldx, void* qt, int64_t ldq, float* scales, void* exps, unsigned* amax_ws, int R, int C,
+                                      int dt, void* stream) {
+  if (!x || !qt || !scales || !exps || !amax_ws || R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldq & 15) || !aligned16(x) || !aligned16(qt)) return MH_ERR_ARG;
+  const int64_t Rp = (int64_t)(R + 127) / 128 * 128;
+  if (ldq < Rp || Rp > 24576) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int64_t G = ((Rp / 128) * 64 + 4095) / 4096 * 4096;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(amax_ws, 0, (size_t)C * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  const int ncv = C / 8;
+  int ry = (R + 63) / 64;
+  if (ry > 512) ry = 512;
+  const dim3 g1((ncv + 255) / 256, ry), g2((C + 63) / 64, (R + 127) / 128);
+  if (dt == MH_BF16) {
+    hipLaunchKernelGGL(col_absmax_k<MH_BF16>, g1, dim3(256), 0, st, (const uint16_t*)x, ldx, amax_ws, R, C);
+    hipLaunchKernelGGL(amax_to_scale_k, dim3((C + 255) / 256), dim3(256), 0, st, (const unsigned*)amax_ws, scales, C);
+    hipLaunchKernelGGL(quant_fp8_transposed_e4_k<MH_BF16>, g2, dim3(256), 0, st, (const uint16_t*)x, ldx, (const float*)scales, (uint8_t*)qt, ldq, (uint8_t*)exps, G, R, C);
+  } else {
+    hipLaunchKernelGGL(col_absmax_k<MH_F16>, g1, dim3(256), 0, st, (const uint16_t*)x, ldx, amax_ws, R, C);
+    hipLaunchKernelGGL(amax_to_scale_k, dim3((C + 255) / 256), dim3(256), 0, st, (const unsigned*)amax_ws, scales, C);
+    hipLaunchKernelGGL(quant_fp8_transposed_e4_k<MH_F16>, g2, dim3(256), 0, st, (const uint16_t*)x, ldx, (const float*)scales, (uint8_t*)qt, ldq, (uint8_t*)exps, G, R, C);
+  }
+  MH_LAUNCH_CHECK();
+}
+
 // x [R, C] -> (q [R, ldq] row-quantised, sr [R]) and (qt [C, ldqt >= round_up(R, 128)] column-quantised + transposed, sc [C]) with two
 // reads of x (maxima, then both copies) instead of four; ws: R + C uints of scratch.
 extern "C" int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc,

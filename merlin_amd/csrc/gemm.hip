@@ -272,47 +272,47 @@ extern "C" int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ld
   MH_LAUNCH_CHECK();
 }
 
-static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
                          int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
                          int epilogue, const RopeSpec& fx, void* stream);
 
-extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
-                           int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
+extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp,
+                           void* C, int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
                            int epilogue, void* stream) {
-  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, C, ldc, bias, resid, ldr, M, N, K, dt_out, epilogue, RopeSpec(), stream);
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, b_exp, C, ldc, bias, resid, ldr, M, N, K, dt_out, epilogue, RopeSpec(), stream);
 }
 // fp8 forms of mh_gemm_nt_rope / mh_gemm_swiglu_fwd (same staged store phases)
-extern "C" int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
-                                int64_t ldc, int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols,
+extern "C" int mh_gemm_fp8_rope(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp,
+                                void* C, int64_t ldc, int M, int N, int K, int dt_out, const float* cos_sin, int S, int D, int rope_cols,
                                 void* stream) {
   if (!cos_sin || S <= 0 || (D != 128 && D != 64) || rope_cols <= 0 || rope_cols > N || (rope_cols % D) || (N & 7) || (ldc & 7) ||
       ((((uintptr_t)C) & 15u) != 0))
     return MH_ERR_ARG;
   RopeSpec r;
   r.tab = cos_sin; r.S = S; r.D = D; r.cols = rope_cols;
-  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, C, ldc, nullptr, nullptr, 0, M, N, K, dt_out, 0, r, stream);
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, b_exp, C, ldc, nullptr, nullptr, 0, M, N, K, dt_out, 0, r, stream);
 }
 extern "C" int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb,
-                                      void* gu, int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out,
+                                      const void* b_exp, void* gu, int64_t ldgu, void* act, int64_t ldact, int M, int ff, int K, int dt_out,
                                       void* stream) {
   if (!gu || !act || ff <= 0 || (ff & 7) || (ldgu & 7) || (ldact & 7) || ((((uintptr_t)gu) | ((uintptr_t)act)) & 15u)) return MH_ERR_ARG;
   RopeSpec r;
   r.sw_mode = 1; r.sw_ff = ff; r.sw_out = act; r.sw_ldo = ldact;
-  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, gu, ldgu, nullptr, nullptr, 0, M, 2 * ff, K, dt_out, 0, r, stream);
+  return gemm_fp8_impl(A8, lda, sa, B8, ldb, sb, b_exp, gu, ldgu, nullptr, nullptr, 0, M, 2 * ff, K, dt_out, 0, r, stream);
 }
 
 // fp8 form of mh_gemm_swiglu_bwd: dact[M, ff] = (sdy qdy)[M, K] (swt qwt)[ff, K]^T with qwt = rowquant(down_proj.weight^T)
 // ([ff, d_model]: contraction over d_model), SwiGLU backward in the store phase (dact never reaches memory).
 extern "C" int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt,
-                                      const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out,
-                                      void* stream) {
+                                      const void* wt_exp, const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K,
+                                      int dt_out, void* stream) {
   if (!gu || !dgu || ff <= 0 || (ff & 7) || (ldgu & 7) || (lddgu & 7) || ((((uintptr_t)gu) | ((uintptr_t)dgu)) & 15u)) return MH_ERR_ARG;
   RopeSpec r;
   r.sw_mode = 2; r.sw_ff = ff; r.sw_out = dgu; r.sw_ldo = lddgu; r.sw_in = gu; r.sw_ldi = ldgu;
-  return gemm_fp8_impl(dy8, lddy, sdy, WdT8, ldw, swt, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt_out, 0, r, stream);
+  return gemm_fp8_impl(dy8, lddy, sdy, WdT8, ldw, swt, wt_exp, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt_out, 0, r, stream);
 }
 
-static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, void* C,
+static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
                          int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
                          int epilogue, const RopeSpec& fx, void* stream) {
   if (!A8 || !B8 || !sa || !sb || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
@@ -333,6 +333,8 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   g.rope_tab = fx.tab; g.rope_S = fx.S; g.rope_D = fx.D; g.rope_cols = fx.cols;
   g.sw_mode = fx.sw_mode; g.sw_ff = fx.sw_ff; g.sw_out = fx.sw_out; g.sw_in = fx.sw_in; g.sw_ldo = fx.sw_ldo; g.sw_ldi = fx.sw_ldi;
   g.sc_m = sa; g.sc_n = sb;
+  g.sc_e = (const uint8_t*)b_exp;
+  g.sc_e_group = ((K / 128) * 64 + 4095) / 4096 * 4096;
   {
     static void* zp = nullptr;
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
@@ -392,7 +394,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split;
-  g.sc_m = nullptr; g.sc_n = nullptr;
+  g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_group = 0;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;
   {

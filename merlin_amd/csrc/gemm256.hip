@@ -55,6 +55,7 @@ constexpr int STAGE256 = 4 * HALF_BYTES;  // A0 A1 B0 B1
 constexpr int H_A0 = 0, H_A1 = 1, H_B0 = 2, H_B1 = 3;
 constexpr int C_ROW = 528;                 // C staging row: 256 x 16-bit + 16 B pad
 constexpr int LDS256 = 256 * C_ROW;        // >= 2 * STAGE256: two stages during the loop, the C tile after it
+constexpr int F8_EXP_BYTES = 2 * 12288;    // fp8: block-exponent images of the two B groups, K <= 24 576 (160 KiB - LDS256 = 28 672)
 
 #define MH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define MH_BAR()                         \
@@ -107,18 +108,22 @@ __device__ __forceinline__ void read_frags_tr(FR& fr, const unsigned* at) {
 // rate probed in tools/probes/f8f6f4_probe.py): one MFMA per accumulator tile and K-tile, same bytes per phase, twice
 // the k.  Hardware block scales are left at 1.0; per-row scales are applied to the accumulators after the loop.
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4_t mfma_f8(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4_t c) {
+// `sa` = E8M0 block scale (2^(sa-127)) of the FIRST operand's 128 k, one value per lane = per row (lane & 15) of the fragment; every
+// lane group of a row supplies the same exponent, i.e. one scale per (row, 128-k block): the per-128-block weight scales of BASELINE
+// cfg 5 applied by the MFMA itself (probe: profiles/r01_f8f6f4_probe.txt).  The second operand's block scale stays 1.0.
+__device__ __forceinline__ f32x4_t mfma_f8(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4_t c, int sa) {
   const i32x8_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
   const i32x8_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, 127);
 }
+__device__ __forceinline__ void lds_read_u8(unsigned& d, unsigned addr) { asm volatile("ds_read_u8 %0, %1" : "=v"(d) : "v"(addr)); }
 #define MFMA_QUAD(MH, NH, bf)                                                               \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
     if constexpr (F8) {                                                                     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
-          acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j]); \
+          acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j], esc[NH][j]); \
     } else {                                                                                \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
@@ -223,6 +228,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
 
   u32x4 af[4][2], b0f[2][2], b1f[2][2];
 
+  // fp8: per-(row, 128-k block) weight exponents (4-bit, scale 2^-e, two rows per byte) of the tile's two 128-row B groups, staged ONCE
+  // behind the operand stages: LDS [2 groups][nk][64 B].  They are the first LDS-DMA copies the block issues, so (in-order completion)
+  // they have landed whenever the first operand half-tile has.  No exponents given: the image is zero (scale 1).
+  int esc[2][2] = {{127, 127}, {127, 127}};
+  unsigned e_lane = 0, e_raw[2][2];
+  const int e_shift = (frow & 1) * 4;
+  if constexpr (F8) {
+    char* eimg = smem + LDS256;
+    const int gp = g.sc_e_group;  // bytes per group image (multiple of 4096, >= nk * 64)
+    const int grp = wave >> 2, wq = wave & 3;
+    if (g.sc_e) {
+      const uint8_t* src = g.sc_e + (int64_t)((grp ? nB1 : n0) >> 7) * gp;
+      for (int c = 0; c < gp; c += 4096) glds16(src + c + wq * 1024 + lane * 16, eimg + grp * gp + c + wq * 1024);
+    } else {
+      for (int c = 0; c < gp; c += 4096) *(uint4*)(eimg + grp * gp + c + wq * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stores are complete before the prologue's barrier publishes them
+    }
+    e_lane = lds0 + LDS256 + wn * 16 + (frow >> 1);
+  }
+
   // prologue: 6 half-tiles in consumption order; A0(0), B0(0) landed for everyone before the first read
   issue(H_A0, 0); issue(H_B0, 0); issue(H_B1, 0); issue(H_A1, 0); issue(H_A0, 1); issue(H_B0, 1);
   MH_WAIT_VM(8);
@@ -242,10 +267,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     // ---- phase 0: quadrant (A0, B0) ----
     if constexpr (AKS) read_frags_tr<0, 4>(af, atA); else READ_A(0);
     if constexpr (BKS) read_frags_tr<32768, 2>(b0f, atB); else READ_B(b0f, 32768);
+    if constexpr (F8) {
+      const unsigned ea = e_lane + (unsigned)kt * 64;
+      lds_read_u8(e_raw[0][0], ea);
+      lds_read_u8(e_raw[0][1], ea + 8);
+      lds_read_u8(e_raw[1][0], ea + (unsigned)g.sc_e_group);
+      lds_read_u8(e_raw[1][1], ea + (unsigned)g.sc_e_group + 8);
+    }
     issue(H_B1, kt + 1);
     MH_WAIT_VM(8);
     MH_BAR();
     MH_LGKM0();
+    if constexpr (F8) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) esc[b][j] = 127 - (int)((e_raw[b][j] >> e_shift) & 15u);
+    }
     MFMA_QUAD(0, 0, b0f);
     MH_BAR();
 
@@ -463,10 +501,11 @@ template <int DT>
 int launch_f8(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_256<DT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+    hipFuncSetAttribute((const void*)gemm_nt_256<DT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256 + F8_EXP_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256, stream, g);
+  if (2 * g.sc_e_group > F8_EXP_BYTES || (g.sc_e_group & 4095) || g.sc_e_group < ((g.K * 2 + 127) / 128) * 64) return MH_ERR_SHAPE;
+  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256 + 2 * g.sc_e_group, stream, g);
   MH_LAUNCH_CHECK();
 }
 // fp8 operands: g.A / g.B point at bytes, g.K, g.lda, g.ldb are in 2-BYTE units (K/2 etc.), dt = output type

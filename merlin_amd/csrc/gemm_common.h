@@ -25,6 +25,10 @@ struct GemmArgs {
   // never stored; sw_out = dgu [M, 2 ff] from sw_in = gu [M, 2 ff].
   const float* sc_m;  // fp8 operand form: per-row scales of A [M] and B [N] (applied to the accumulators)
   const float* sc_n;
+  // fp8: optional per-(row, 128-k block) exponents of B (4-bit e, scale 2^-e relative to sc_n[row]; two rows per byte):
+  // image [N / 128 groups][sc_e_group bytes], a group = [K / 128][64 B]; sc_e_group = round_up(K / 128 * 64, 4096)
+  const uint8_t* sc_e;
+  int sc_e_group;
   int sw_mode, sw_ff;
   void* sw_out;
   const void* sw_in;

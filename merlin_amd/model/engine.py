@@ -422,8 +422,8 @@ class HipEngine:
         """fp8 (e4m3, one scale per output channel) copies of the decoder's Linear weights for the fp8 FORWARD (inference /
         prefill form of BASELINE cfg 5's fp8 MFMA weight path).  Re-run after the weights change."""
         self.ensure_arena()
-        self._fp8_fwd = [dict(wqkv=O.quant_fp8_rows(W.wqkv), wo=O.quant_fp8_rows(W.wo), wgu=O.quant_fp8_rows(W.wgu),
-                              wd=O.quant_fp8_rows(W.wd)) for W in self.llama]
+        self._fp8_fwd = [dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), wgu=O.quant_fp8_rows_e4(W.wgu),
+                              wd=O.quant_fp8_rows_e4(W.wd)) for W in self.llama]
         return self._fp8_fwd
 
     def _llama_layer_fwd_fp8(self, W, Q, x, B, S, lens, kv_out=None):
@@ -455,9 +455,10 @@ class HipEngine:
         def make():
             out = []
             for W in self.llama:
-                out.append(dict(wqkv=O.quant_fp8_rows(W.wqkv), wo=O.quant_fp8_rows(W.wo), wgu=O.quant_fp8_rows(W.wgu), wd=O.quant_fp8_rows(W.wd),
-                                wqkvT=O.quant_fp8_rows_t(W.wqkv), woT=O.quant_fp8_rows_t(W.wo), wguT=O.quant_fp8_rows_t(W.wgu),
-                                wdT=O.quant_fp8_rows_t(W.wd)))
+                # weights: per-row fp32 scale + per-128-block exponents (applied by the MFMA's block-scale operand)
+                out.append(dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), wgu=O.quant_fp8_rows_e4(W.wgu), wd=O.quant_fp8_rows_e4(W.wd),
+                                wqkvT=O.quant_fp8_rows_t_e4(W.wqkv), woT=O.quant_fp8_rows_t_e4(W.wo), wguT=O.quant_fp8_rows_t_e4(W.wgu),
+                                wdT=O.quant_fp8_rows_t_e4(W.wd)))
             return out
         return self._derive("fp8_train_weights", make)[li]
 

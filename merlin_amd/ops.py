@@ -317,6 +317,43 @@ def quant_fp8_rows(x):
 _amax_ws = {}
 
 
+def _b3(b8):
+    """(q, row scales[, block exponents]) -> always a triple."""
+    return (b8[0], b8[1], b8[2] if len(b8) > 2 else None)
+
+
+def _exp_image(n_rows, k, device):
+    G = round_up((k // 128) * 64, 4096)
+    return torch.zeros(((n_rows + 255) // 256) * 2, G, dtype=torch.uint8, device=device)
+
+
+def quant_fp8_rows_e4(w):
+    """Weights for the fp8 GEMMs: w [N, K] -> (q uint8 [N, K] e4m3, s fp32 [N], exps): per-row scale s[n] and a 4-bit exponent per
+    (row, 128-k block), block scale = s[n] * 2^-e - BASELINE cfg 5's per-128-block scales in the form the MFMA applies itself."""
+    N, K = w.shape
+    assert K % 128 == 0 and w.stride(1) == 1
+    q = torch.empty(N, K, dtype=torch.uint8, device=w.device)
+    sc = torch.empty(N, dtype=torch.float32, device=w.device)
+    ex = _exp_image(N, K, w.device)
+    L.check(L.lib().mh_quant_fp8_rows_e4(p(w), i64(_rowmajor(w)), p(q), p(sc), p(ex), i32(N), i32(K), i32(dt_of(w)), _stream()), "mh_quant_fp8_rows_e4")
+    return q, sc, ex
+
+
+def quant_fp8_rows_t_e4(w):
+    """w [R, C] -> (qt [C, round_up(R, 128)], s [C], exps): the same format for w^T (rows = input channels, blocks of 128 output channels)."""
+    R, C_ = w.shape
+    Rp = round_up(R, 128)
+    qt = torch.empty(C_, Rp, dtype=torch.uint8, device=w.device)
+    sc = torch.empty(C_, dtype=torch.float32, device=w.device)
+    ex = _exp_image(C_, Rp, w.device)
+    ws = _amax_ws.get((w.device, C_))
+    if ws is None:
+        ws = _amax_ws[(w.device, C_)] = torch.empty(C_, dtype=torch.int32, device=w.device)
+    L.check(L.lib().mh_quant_fp8_rows_t_e4(p(w), i64(_rowmajor(w)), p(qt), i64(Rp), p(sc), p(ex), p(ws), i32(R), i32(C_), i32(dt_of(w)), _stream()),
+            "mh_quant_fp8_rows_t_e4")
+    return qt, sc, ex
+
+
 def quant_fp8_rows_t(x):
     """x [R, C] (16-bit) -> (qt uint8 [C, round_up(R, 128)] = e4m3(x^T / s), s fp32 [C]): the column-scaled TRANSPOSED operand
     (zero-filled pad columns) the wgrad / dgrad GEMMs of the fp8 training step contract over."""
@@ -368,20 +405,20 @@ def quant_fp8_t_from_rows(x, row_scales):
 
 def gemm_fp8_swiglu_bwd(dy8, wdt8, gu):
     """dgu = swiglu_bwd(gu, dy Wd) on the scaled-fp8 MFMA; dy8 = rowquant(dy) [T, d], wdt8 = rowquant(Wd^T) [ff, d]."""
-    (qa, sa), (qb, sb) = dy8, wdt8
+    (qa, sa), (qb, sb, eb) = dy8[:2], _b3(wdt8)
     M, K = qa.shape
     ff = qb.shape[0]
     assert qb.shape[1] == K and gu.shape == (M, 2 * ff)
     dgu = torch.empty_like(gu)
     with _timed("gemm_fp8", 2.0 * M * ff * K):
-        L.check(L.lib().mh_gemm_fp8_swiglu_bwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(gu), i64(_rowmajor(gu)),
+        L.check(L.lib().mh_gemm_fp8_swiglu_bwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(gu), i64(_rowmajor(gu)),
                                                p(dgu), i64(_rowmajor(dgu)), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()), "mh_gemm_fp8_swiglu_bwd")
     return dgu
 
 
 def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None, accum=False):
     """out[M, N] = (sa qa) @ (sb qb)^T on the scaled-fp8 MFMA; a8 = (qa [M, K] uint8, sa [M]), b8 = (qb [N, K], sb [N])."""
-    (qa, sa), (qb, sb) = a8, b8
+    (qa, sa), (qb, sb, eb) = a8[:2], _b3(b8)
     M, K = qa.shape
     N = qb.shape[0]
     assert qb.shape[1] == K
@@ -399,32 +436,32 @@ def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, 
         assert out is not None
         epi |= EPI_ACCUM
     with _timed("gemm_fp8", 2.0 * M * N * K):
-        L.check(L.lib().mh_gemm_fp8(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(out), i64(_rowmajor(out)), p(bias),
+        L.check(L.lib().mh_gemm_fp8(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(out), i64(_rowmajor(out)), p(bias),
                                     p(resid), i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(out)), i32(epi), _stream()), "mh_gemm_fp8")
     return out
 
 
 def gemm_fp8_rope(a8, b8, table, S, H, D, out_dtype=torch.bfloat16):
     """fp8 q|k|v projection with RoPE in the epilogue (see gemm_nt_rope)."""
-    (qa, sa), (qb, sb) = a8, b8
+    (qa, sa), (qb, sb, eb) = a8[:2], _b3(b8)
     M, K = qa.shape
     N = qb.shape[0]
     out = torch.empty(M, N, dtype=out_dtype, device=qa.device)
     with _timed("gemm_fp8", 2.0 * M * N * K):
-        L.check(L.lib().mh_gemm_fp8_rope(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(out), i64(N), i32(M), i32(N),
+        L.check(L.lib().mh_gemm_fp8_rope(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(out), i64(N), i32(M), i32(N),
                                          i32(K), i32(dt_of(out)), p(table), i32(S), i32(D), i32(2 * H * D), _stream()), "mh_gemm_fp8_rope")
     return out
 
 
 def gemm_fp8_swiglu_fwd(a8, b8, out_dtype=torch.bfloat16):
     """fp8 gate|up projection with SwiGLU in the epilogue (see gemm_swiglu_fwd).  Returns (gu, act)."""
-    (qa, sa), (qb, sb) = a8, b8
+    (qa, sa), (qb, sb, eb) = a8[:2], _b3(b8)
     M, K = qa.shape
     ff = qb.shape[0] // 2
     gu = torch.empty(M, 2 * ff, dtype=out_dtype, device=qa.device)
     act = torch.empty(M, ff, dtype=out_dtype, device=qa.device)
     with _timed("gemm_fp8", 2.0 * M * 2 * ff * K):
-        L.check(L.lib().mh_gemm_fp8_swiglu_fwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(gu), i64(2 * ff), p(act),
+        L.check(L.lib().mh_gemm_fp8_swiglu_fwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(gu), i64(2 * ff), p(act),
                                                i64(ff), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()), "mh_gemm_fp8_swiglu_fwd")
     return gu, act
 

@@ -119,6 +119,88 @@ def test_rmsnorm_with_fused_row_quantisation_is_bit_identical(dtype, rows, d):
     assert torch.equal(y, y0) and torch.equal(s, s0) and torch.equal(q, q0)
 
 
+def _deq_e4(q, s, ex, n_rows, K):
+    """dequantise (q [N, K] e4m3 bytes, s [N], exponent image) -> fp32 [N, K]"""
+    G = ex.shape[1]
+    nkb = K // 128
+    rows = torch.arange(n_rows, device=q.device)
+    img = ex[(rows >> 7)].view(n_rows, G)[:, : nkb * 64].reshape(n_rows, nkb, 64)
+    byte = img[rows[:, None], torch.arange(nkb, device=q.device)[None, :], ((rows & 127) >> 1)[:, None]]
+    e = (byte >> ((rows & 1) * 4)[:, None]) & 15
+    scale = s[:, None] * torch.pow(2.0, -e.float())                                   # [N, nkb]
+    return q.view(torch.float8_e4m3fn).float().view(n_rows, nkb, 128) * scale[:, :, None], e
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(256, 256), (520, 384), (4096, 4096), (1000, 11008), (11008, 4096)])
+def test_weight_quantisation_with_per_128_block_exponents(dtype, N, K):
+    """BASELINE cfg 5: "fp8-e4m3 weights (per-128-block scales)".  Row scale s[n] = rowmax / 448 and a 4-bit exponent per (row, 128-k
+    block): e = floor(log2(rowmax / blockmax)) (so every block's scaled maximum lies in (224, 448]), q = e4m3(w 2^e / s); both the
+    row-major form (forward) and the transposed form (dgrad) of a weight."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.02).to(dtype)
+    w[:, 128:256] *= 0.01   # a block far below the row maximum: tensor / row scaling alone would crush it
+    w[3, :128] = 0
+    q, s, ex = O.quant_fp8_rows_e4(w)
+    assert torch.allclose(s, w.float().abs().amax(dim=1) / 448.0, rtol=1e-6)
+    deq, e = _deq_e4(q, s, ex, N, K)
+    bmax = w.float().abs().view(N, K // 128, 128).amax(dim=2)
+    rmax = w.float().abs().amax(dim=1, keepdim=True)
+    e_ref = torch.where(bmax > 0, torch.floor(torch.log2(rmax / bmax.clamp_min(1e-38))).clamp(0, 15), torch.full_like(bmax, 15)).long()
+    assert int((e.long() - e_ref).abs().max()) <= 1 and float((e.long() != e_ref).float().mean()) < 1e-3  # (log2 at exact powers of two)
+    err = (deq.view(N, K) - w.float()).abs().view(N, K // 128, 128).amax(dim=2)
+    ok = err <= bmax * 2.0 ** -4 + 1e-12                                     # e4m3: <= 2^-4 relative to the BLOCK maximum, small blocks included
+    assert bool(ok.all())
+    assert float(err[:, 1].max()) < float(rmax.max()) * 2.0 ** -9            # the 100x smaller block kept its precision
+    # transposed form: rows = input channels k, blocks of 128 output channels n
+    qt, st, ext = O.quant_fp8_rows_t_e4(w)
+    Np = (N + 127) // 128 * 128
+    assert qt.shape == (K, Np) and torch.allclose(st, w.float().abs().amax(dim=0) / 448.0, rtol=1e-6)
+    deqt, _ = _deq_e4(qt, st, ext, K, Np)
+    wt = torch.zeros(K, Np, device="cuda")
+    wt[:, :N] = w.float().t()
+    errt = (deqt.view(K, Np) - wt).abs().view(K, Np // 128, 128).amax(dim=2)
+    assert bool((errt <= wt.abs().view(K, Np // 128, 128).amax(dim=2) * 2.0 ** -4 + 1e-12).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 384), (1000, 520, 256), (613, 4096, 1024), (4096, 4096, 4096), (2048, 4096, 11008),
+                                   (1024, 4096, 22016)])
+def test_fp8_gemm_with_block_scaled_weights(dtype, M, N, K):
+    """The scaled-fp8 MFMA with the weights' per-128-block exponents in its E8M0 block-scale operand: exact against the fp32 product of
+    the dequantised operands, and closer to the unquantised product than per-row scaling when blocks differ in magnitude."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, device="cuda").to(dtype)
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(dtype)
+    w.view(N, K // 128, 128)[:, 1::2] *= 2.0 ** -7
+    qa = O.quant_fp8_rows(a)
+    qw = O.quant_fp8_rows_e4(w)
+    da = qa[0].view(torch.float8_e4m3fn).float() * qa[1][:, None]
+    dw, _ = _deq_e4(*qw, N, K)
+    ref = da @ dw.view(N, K).t()
+    out = O.gemm_fp8(qa, qw, out_dtype=dtype)
+    assert _relerr(out, ref) < 3 * EPS[dtype]
+    assert torch.equal(O.gemm_fp8(qa, qw, out_dtype=dtype), out)
+    full = a.float() @ w.float().t()
+    plain = O.gemm_fp8(qa, O.quant_fp8_rows(w), out_dtype=dtype)
+    e_block, e_row = float((out.float() - full).pow(2).mean().sqrt()), float((plain.float() - full).pow(2).mean().sqrt())
+    assert e_block <= e_row * 1.02, (e_block, e_row)
+    if N % 4 == 0:
+        resid = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+        assert _relerr(O.gemm_fp8(qa, qw, out_dtype=dtype, resid=resid), ref + resid.float()) < 4 * EPS[dtype]
+    # dgrad form: dy [M, N] x rowquant_e4(w^T) [K, Np]
+    if N % 128 == 0:
+        dy = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+        qd, qwt = O.quant_fp8_rows(dy), O.quant_fp8_rows_t_e4(w)
+        dd = qd[0].view(torch.float8_e4m3fn).float() * qd[1][:, None]
+        dwt, _ = _deq_e4(*qwt, K, N)
+        assert _relerr(O.gemm_fp8(qd, qwt, out_dtype=dtype), dd @ dwt.view(K, N).t()) < 3 * EPS[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_swiglu_backward_fused_matches_unfused(dtype):
     from merlin_amd import ops as O

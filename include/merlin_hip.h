@@ -108,8 +108,10 @@ int mh_gemm_fp8_swiglu_fwd(const void* A8, int64_t lda, const float* sa, const v
 /* b_exp (nullable, all four fp8 GEMM entry points): per-128-block scales of the B operand (the weights) - BASELINE cfg 5's
  * "per-128-block scales" - as 4-bit exponents e, block scale = sb[n] * 2^-e, applied by the MFMA's own E8M0 block-scale operand
  * (v_mfma_scale_f32_16x16x128_f8f6f4) at no cost in the K loop.  Layout produced by mh_quant_fp8_rows_e4 / mh_quant_fp8_rows_t_e4:
- * [ceil(N / 256) * 2 groups of 128 rows][G bytes], G = round_up(K / 128 * 64, 4096), a group = [K / 128 blocks][64 B], two rows per
- * byte (low nibble = even row).  K <= 24 576. */
+ * a 16-byte header (int32 flag "some exponent is non-zero", raised by the quantiser - the GEMM takes its constant-scale loop while it is
+ * 0, e.g. for i.i.d. initialised weights - then padding; ZERO the header before quantising) followed by [ceil(N / 256) * 2 groups of
+ * 128 rows][G bytes], G = round_up(K / 128 * 64, 4096), a group = [K / 128 blocks][64 B], two rows per byte (low nibble = even row).
+ * K <= 24 576. */
 int mh_quant_fp8_rows_e4(const void* w, int64_t ldw, void* q, float* scales, void* exps, int N, int K, int dt, void* stream);
 int mh_quant_fp8_rows_t_e4(const void* w, int64_t ldw, void* qt, int64_t ldq, float* scales, void* exps, unsigned* amax_ws, int R, int C, int dt,
                            void* stream);

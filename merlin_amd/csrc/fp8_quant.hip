@@ -93,7 +93,9 @@ __device__ __forceinline__ int block_exp(float rowmax, float bmax) {
 // one wave per PAIR of rows (2p, 2p + 1): the two rows share every exponent byte
 template <int DT>
 __global__ __launch_bounds__(256) void quant_fp8_rows_e4_k(const uint16_t* __restrict__ w, int64_t ldw, uint8_t* __restrict__ q, float* __restrict__ sc,
-                                                           uint8_t* __restrict__ ex, int64_t G, int N, int K) {
+                                                           uint8_t* __restrict__ exh, int64_t G, int N, int K) {
+  int* flag = (int*)exh;          // 16-byte header: "some exponent is non-zero"
+  uint8_t* ex = exh + 16;
   const int lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
   if (n0 >= N) return;
@@ -131,7 +133,10 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_e4_k(const uint16_t* __res
     const int e0 = block_exp(m0, b0), e1 = two ? block_exp(m1, b1) : 0;
     const float i0 = ldexpf(1.0f / s0, e0), i1 = ldexpf(1.0f / s1, e1);
     const int kb = c >> 4;
-    if ((lane & 15) == 0) eb[(int64_t)kb * 64] = (uint8_t)(e0 | (e1 << 4));
+    if ((lane & 15) == 0) {
+      eb[(int64_t)kb * 64] = (uint8_t)(e0 | (e1 << 4));
+      if ((e0 | e1) != 0 && *flag == 0) atomicOr(flag, 1);
+    }
     int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[0] * i0, f0[1] * i0, 0, false);
     p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[2] * i0, f0[3] * i0, p0, true);
     int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f0[4] * i0, f0[5] * i0, 0, false);
@@ -151,7 +156,9 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_e4_k(const uint16_t* __res
 // every output row it touches, so the block maximum is a reduction inside the tile
 template <int DT>
 __global__ __launch_bounds__(256) void quant_fp8_transposed_e4_k(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ sc,
-                                                                 uint8_t* __restrict__ qt, int64_t ldq, uint8_t* __restrict__ ex, int64_t G, int R, int C) {
+                                                                 uint8_t* __restrict__ qt, int64_t ldq, uint8_t* __restrict__ exh, int64_t G, int R, int C) {
+  int* flag = (int*)exh;
+  uint8_t* ex = exh + 16;
   __shared__ unsigned tile[64][33];
   __shared__ float wmax[4][64];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 128;
@@ -192,7 +199,10 @@ __global__ __launch_bounds__(256) void quant_fp8_transposed_e4_k(const uint16_t*
     inv[j] = ldexpf(1.0f / s, e);
     ebytes |= (unsigned)e << (4 * j);  // nibble j: columns col + j, i.e. byte j/2, low nibble = even column
   }
-  if (rq == 0 && col < C) *(unsigned*)(ex + (int64_t)(col >> 7) * G + (int64_t)blockIdx.y * 64 + ((col & 127) >> 1)) = ebytes;
+  if (rq == 0 && col < C) {
+    *(unsigned*)(ex + (int64_t)(col >> 7) * G + (int64_t)blockIdx.y * 64 + ((col & 127) >> 1)) = ebytes;
+    if (ebytes != 0 && *flag == 0) atomicOr(flag, 1);
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0][j] * inv[j], v[1][j] * inv[j], 0, false);

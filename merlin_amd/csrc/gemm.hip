@@ -333,8 +333,11 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   g.rope_tab = fx.tab; g.rope_S = fx.S; g.rope_D = fx.D; g.rope_cols = fx.cols;
   g.sw_mode = fx.sw_mode; g.sw_ff = fx.sw_ff; g.sw_out = fx.sw_out; g.sw_in = fx.sw_in; g.sw_ldo = fx.sw_ldo; g.sw_ldi = fx.sw_ldi;
   g.sc_m = sa; g.sc_n = sb;
-  g.sc_e = (const uint8_t*)b_exp;
-  g.sc_e_group = ((K / 128) * 64 + 4095) / 4096 * 4096;
+  // b_exp: 16-byte header (int32 "any exponent non-zero" flag written by the quantiser + padding), then the exponent image
+  g.sc_e = b_exp ? (const uint8_t*)b_exp + 16 : nullptr;
+  g.sc_e_flag = (const int*)b_exp;
+  g.sc_e_group = b_exp ? ((K / 128) * 64 + 4095) / 4096 * 4096 : 0;
+  if (b_exp && (((uintptr_t)b_exp) & 15u)) return MH_ERR_ARG;
   {
     static void* zp = nullptr;
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess) return MH_ERR_ARG;
@@ -394,7 +397,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split;
-  g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_group = 0;
+  g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_flag = nullptr; g.sc_e_group = 0;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;
   {

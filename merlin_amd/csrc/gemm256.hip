@@ -123,7 +123,7 @@ __device__ __forceinline__ void lds_read_u8(unsigned& d, unsigned addr) { asm vo
     if constexpr (F8) {                                                                     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
-          acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j], esc[NH][j]); \
+          acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j], ESC ? esc[NH][j] : 127); \
     } else {                                                                                \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
@@ -231,21 +231,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   // fp8: per-(row, 128-k block) weight exponents (4-bit, scale 2^-e, two rows per byte) of the tile's two 128-row B groups, staged ONCE
   // behind the operand stages: LDS [2 groups][nk][64 B].  They are the first LDS-DMA copies the block issues, so (in-order completion)
   // they have landed whenever the first operand half-tile has.  No exponents given: the image is zero (scale 1).
+  // The quantiser raises *sc_e_flag when any exponent is non-zero; weights whose blocks all sit within a factor 2 of their row maximum
+  // (e = 0 everywhere, e.g. i.i.d. initialised weights) take the loop variant with constant block scales (wave-uniform branch).
   int esc[2][2] = {{127, 127}, {127, 127}};
   unsigned e_lane = 0, e_raw[2][2];
   const int e_shift = (frow & 1) * 4;
+  bool use_exp = false;
   if constexpr (F8) {
-    char* eimg = smem + LDS256;
-    const int gp = g.sc_e_group;  // bytes per group image (multiple of 4096, >= nk * 64)
-    const int grp = wave >> 2, wq = wave & 3;
-    if (g.sc_e) {
+    use_exp = g.sc_e && (!g.sc_e_flag || __builtin_amdgcn_readfirstlane(*g.sc_e_flag) != 0);
+    if (use_exp) {
+      char* eimg = smem + LDS256;
+      const int gp = g.sc_e_group;  // bytes per group image (multiple of 4096, >= nk * 64)
+      const int grp = wave >> 2, wq = wave & 3;
       const uint8_t* src = g.sc_e + (int64_t)((grp ? nB1 : n0) >> 7) * gp;
       for (int c = 0; c < gp; c += 4096) glds16(src + c + wq * 1024 + lane * 16, eimg + grp * gp + c + wq * 1024);
-    } else {
-      for (int c = 0; c < gp; c += 4096) *(uint4*)(eimg + grp * gp + c + wq * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stores are complete before the prologue's barrier publishes them
+      e_lane = lds0 + LDS256 + wn * 16 + (frow >> 1);
     }
-    e_lane = lds0 + LDS256 + wn * 16 + (frow >> 1);
   }
 
   // prologue: 6 half-tiles in consumption order; A0(0), B0(0) landed for everyone before the first read
@@ -254,6 +255,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   MH_BAR();
   if (wm == 1) MH_BAR();  // the wm=1 group runs one barrier behind
 
+  auto k_loop = [&](auto ESC_) {
+  constexpr bool ESC = decltype(ESC_)::value;
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned sb = (unsigned)(kt & 1) * STAGE256;
     const unsigned aA0 = a_row + sb + c0, aA1 = a_row + sb + c1;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     // ---- phase 0: quadrant (A0, B0) ----
     if constexpr (AKS) read_frags_tr<0, 4>(af, atA); else READ_A(0);
     if constexpr (BKS) read_frags_tr<32768, 2>(b0f, atB); else READ_B(b0f, 32768);
-    if constexpr (F8) {
+    if constexpr (ESC) {
       const unsigned ea = e_lane + (unsigned)kt * 64;
       lds_read_u8(e_raw[0][0], ea);
       lds_read_u8(e_raw[0][1], ea + 8);
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     MH_WAIT_VM(8);
     MH_BAR();
     MH_LGKM0();
-    if constexpr (F8) {
+    if constexpr (ESC) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -310,6 +313,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     MH_BAR();
     MFMA_QUAD(1, 0, b0f);
     MH_BAR();
+  }
+  };
+  if constexpr (F8) {
+    if (use_exp) k_loop(std::true_type{}); else k_loop(std::false_type{});
+  } else {
+    k_loop(std::false_type{});
   }
   if (wm == 0) MH_BAR();
   MH_WAIT_VM(0);  // drain the (redundant) tail loads before the block's LDS is released
@@ -504,8 +513,8 @@ int launch_f8(const GemmArgs& g, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt_256<DT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256 + F8_EXP_BYTES);
     attr_set = true;
   }
-  if (2 * g.sc_e_group > F8_EXP_BYTES || (g.sc_e_group & 4095) || g.sc_e_group < ((g.K * 2 + 127) / 128) * 64) return MH_ERR_SHAPE;
-  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256 + 2 * g.sc_e_group, stream, g);
+  if (g.sc_e && (2 * g.sc_e_group > F8_EXP_BYTES || (g.sc_e_group & 4095) || g.sc_e_group < ((g.K * 2 + 127) / 128) * 64)) return MH_ERR_SHAPE;
+  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256 + (g.sc_e ? 2 * g.sc_e_group : 0), stream, g);
   MH_LAUNCH_CHECK();
 }
 // fp8 operands: g.A / g.B point at bytes, g.K, g.lda, g.ldb are in 2-BYTE units (K/2 etc.), dt = output type

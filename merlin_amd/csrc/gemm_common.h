@@ -28,6 +28,7 @@ struct GemmArgs {
   // fp8: optional per-(row, 128-k block) exponents of B (4-bit e, scale 2^-e relative to sc_n[row]; two rows per byte):
   // image [N / 128 groups][sc_e_group bytes], a group = [K / 128][64 B]; sc_e_group = round_up(K / 128 * 64, 4096)
   const uint8_t* sc_e;
+  const int* sc_e_flag;  // device word, non-zero when any exponent of the image is non-zero (written by the quantiser); may be null
   int sc_e_group;
   int sw_mode, sw_ff;
   void* sw_out;

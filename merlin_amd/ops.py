@@ -324,7 +324,7 @@ def _b3(b8):
 
 def _exp_image(n_rows, k, device):
     G = round_up((k // 128) * 64, 4096)
-    return torch.zeros(((n_rows + 255) // 256) * 2, G, dtype=torch.uint8, device=device)
+    return torch.zeros(16 + ((n_rows + 255) // 256) * 2 * G, dtype=torch.uint8, device=device)  # 16-byte flag header + image
 
 
 def quant_fp8_rows_e4(w):

@@ -121,8 +121,10 @@ def test_rmsnorm_with_fused_row_quantisation_is_bit_identical(dtype, rows, d):
 
 def _deq_e4(q, s, ex, n_rows, K):
     """dequantise (q [N, K] e4m3 bytes, s [N], exponent image) -> fp32 [N, K]"""
-    G = ex.shape[1]
     nkb = K // 128
+    G = (nkb * 64 + 4095) // 4096 * 4096
+    assert int(ex[:4].view(torch.int32)) == int(bool(ex[16:].any())), "the header flag says whether any exponent is non-zero"
+    ex = ex[16:].view(-1, G)
     rows = torch.arange(n_rows, device=q.device)
     img = ex[(rows >> 7)].view(n_rows, G)[:, : nkb * 64].reshape(n_rows, nkb, 64)
     byte = img[rows[:, None], torch.arange(nkb, device=q.device)[None, :], ((rows & 127) >> 1)[:, None]]

@@ -240,6 +240,124 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
   }
 }
 
+
+// ---- 3..16 activation rows: the matrix cores do the multiplies --------------------------------------------------------------------
+// At batch 1-2 the one-wave-per-row kernel above is HBM-bound; from ~4 rows on its VALU work (rows x 8 dot2 per 16 B of weights, x 2
+// more with fp8 dequantisation) is what limits it.  Here a block owns 16 weight rows and its 8 waves split K: every lane loads 16 B of
+// one weight row STRAIGHT INTO the MFMA's B-operand registers (lane l: row l & 15, k-chunk l >> 4 - no LDS hop for the streamed
+// operand), the <= 16 activation rows are the A operand from an LDS copy (row stride padded by 16 B: conflict-free fragment reads),
+// and one 16x16x32 MFMA per 1 KB of weights replaces 16 x M dot2 instructions: the kernel is HBM-bound for any M <= 16.  fp8 weights
+// (16 values per 16 B, per-128-block fp32 scales) are converted to 16-bit in registers (16 cvt per load instead of 16 x M fma) and
+// their block's partial product is scaled once per load step.  Partial tiles of the 8 waves are summed through LDS in a fixed order.
+constexpr int GM_KC = 2048;            // activation chunk in LDS: 16 rows x (2048 + 8) x 2 B = 65.8 KB
+constexpr int GM_LD = GM_KC + 8;
+template <int DT, bool FP8W>
+__global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ x, int64_t ldx, const void* __restrict__ Wv, int64_t ldw,
+                                                   const float* __restrict__ wsc, void* __restrict__ out, int64_t ldo,
+                                                   const uint16_t* __restrict__ resid, int64_t ldr, int M, int N, int K, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [16][GM_LD], then reused as float red[8][64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16, j = lane & 15, kq = lane >> 4;
+  const int nrow = min(n0 + j, N - 1);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int nb = (K + 127) / 128;
+  for (int kc = 0; kc < K; kc += GM_KC) {
+    const int klen = min(GM_KC, K - kc);
+    if (kc) __syncthreads();
+    for (int i = tid * 8; i < 16 * klen; i += 512 * 8) {
+      const int m = i / klen, k = i - m * klen;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < M) v = *(const uint4*)(x + (int64_t)m * ldx + kc + k);
+      *(uint4*)(xs + m * GM_LD + k) = v;
+    }
+    __syncthreads();
+    if constexpr (!FP8W) {
+      const uint16_t* wr = (const uint16_t*)Wv + (int64_t)nrow * ldw + kc + kq * 8;
+      const uint16_t* xr = xs + j * GM_LD + kq * 8;
+      // steps of 32 k, wave w takes steps w, w + 8, ...; 4 loads in flight per lane
+      for (int k0 = wave * 32; k0 < klen; k0 += 8 * 32 * 4) {
+        uint4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = (k0 + u * 256 < klen) ? *(const uint4*)(wr + k0 + u * 256) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k0 + u * 256 >= klen) break;
+          const uint4 xv = *(const uint4*)(xr + k0 + u * 256);
+          acc = mfma16<DT>(xv, wv[u], acc);
+        }
+      }
+    } else {
+      const uint8_t* wr = (const uint8_t*)Wv + (int64_t)nrow * ldw + kc + kq * 16;   // ldw = K bytes
+      const float* sr = wsc + (int64_t)nrow * nb;
+      const uint16_t* xr = xs + j * GM_LD + kq * 16;
+      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...
+      for (int k0 = wave * 64; k0 < klen; k0 += 8 * 64 * 2) {
+        uint4 qv[2];
+        float sc2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool ok = k0 + u * 512 < klen;
+          qv[u] = ok ? *(const uint4*)(wr + k0 + u * 512) : make_uint4(0, 0, 0, 0);
+          sc2[u] = ok ? sr[(kc + k0 + u * 512) >> 7] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (k0 + u * 512 >= klen) break;
+          float w[16];
+          fp8x4_to_f32(qv[u].x, w); fp8x4_to_f32(qv[u].y, w + 4); fp8x4_to_f32(qv[u].z, w + 8); fp8x4_to_f32(qv[u].w, w + 12);
+          const uint4 b0 = pack8<DT>(w), b1 = pack8<DT>(w + 8);   // e4m3 values are exact in bf16 and fp16
+          const uint4 x0 = *(const uint4*)(xr + k0 + u * 512), x1 = *(const uint4*)(xr + k0 + u * 512 + 8);
+          f32x4_t part = {0.f, 0.f, 0.f, 0.f};
+          part = mfma16<DT>(x0, b0, part);
+          part = mfma16<DT>(x1, b1, part);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = fmaf(sc2[u], part[r], acc[r]);
+        }
+      }
+    }
+  }
+  // D lane l reg r = D[m = 4 * (l >> 4) + r][n = l & 15]: sum the 8 waves' tiles in wave order
+  __syncthreads();
+  float* red = (float*)xs;
+  *(f32x4_t*)(red + (wave * 64 + lane) * 4) = acc;
+  __syncthreads();
+  if (wave == 0) {
+    f32x4_t s4 = *(const f32x4_t*)(red + lane * 4);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      const f32x4_t t = *(const f32x4_t*)(red + (w * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r] += t[r];
+    }
+    const int n = n0 + j;
+    if (n < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * kq + r;
+        if (m >= M) continue;
+        float v = s4[r];
+        if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+        if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+        else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+      }
+    }
+  }
+}
+
+template <int DT, bool FP8W>
+static int launch_gemv_mfma(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* wsc, void* out, int64_t ldo, const void* resid,
+                            int64_t ldr, int M, int N, int K, int out_f32, hipStream_t st) {
+  constexpr int lds = 16 * GM_LD * 2;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W>), dim3((N + 15) / 16), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
+                     (const uint16_t*)resid, ldr, M, N, K, out_f32);
+  MH_LAUNCH_CHECK();
+}
+
 // qkv [B, 3, H, D] of the new tokens; tab [max_pos, D/2] (cos, sin); kc, vc [B, Smax, H*D]
 template <int DT>
 __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv, const float2* __restrict__ tab,
@@ -388,11 +506,20 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 
 }  // namespace
 
+static int g_gemv_mfma_min_rows = 3;
+// A/B switch for kernel development: activation-row count from which mh_gemv / mh_gemv_fp8w use the MFMA form (default 3; 17 = never)
+extern "C" void mh_gemv_mfma_min_rows(int rows) { g_gemv_mfma_min_rows = rows; }
+
 extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
                        int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
-  if (!x || !W || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
+  if (!x || !W || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  if (M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
+    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+    return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+  }
+  if (M > 8) return MH_ERR_ARG;
   // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
   // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
   const int rows = M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1));
@@ -494,9 +621,14 @@ extern "C" int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* sca
 
 extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
                             int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
-  if (!x || !q || !scales || !out || M <= 0 || M > 8 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
+  if (!x || !q || !scales || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  if (M >= g_gemv_mfma_min_rows && (K % 64) == 0) {
+    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+    return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+  }
+  if (M > 8) return MH_ERR_ARG;
   const int rows = M < 3 ? 1 : (N >= 8192 ? 2 : 1);  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv)
   const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
   hipStream_t st = as_stream(stream);

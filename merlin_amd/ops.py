@@ -127,14 +127,14 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
 
 
 def gemv(x, w, out=None, resid=None, out_f32=False, n=None):
-    """out[M, N] = x[M, K] @ w[N, K]^T (+ resid) for M <= 8 rows per launch (decode step): weights streamed once."""
+    """out[M, N] = x[M, K] @ w[N, K]^T (+ resid), <= 16 rows per launch (decode step): weights streamed once per launch."""
     M, K = x.shape
     N = w.shape[0] if n is None else n
     assert w.shape[1] == K and x.dtype == w.dtype
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    for m0 in range(0, M, 8):
-        mm = min(8, M - m0)
+    for m0 in range(0, M, 16):
+        mm = min(16, M - m0)
         xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
         rs = resid[m0:m0 + mm] if resid is not None else None
         L.check(L.lib().mh_gemv(p(xs), i64(_rowmajor(xs)), p(w), i64(_rowmajor(w)), p(os_), i64(_rowmajor(os_)), p(rs),
@@ -160,8 +160,8 @@ def gemv_fp8w(x, qw, out=None, resid=None, out_f32=False, n=None):
     assert q.shape[1] == K
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    for m0 in range(0, M, 8):
-        mm = min(8, M - m0)
+    for m0 in range(0, M, 16):
+        mm = min(16, M - m0)
         xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
         rs = resid[m0:m0 + mm] if resid is not None else None
         L.check(L.lib().mh_gemv_fp8w(p(xs), i64(_rowmajor(xs)), p(q), p(sc), p(os_), i64(_rowmajor(os_)), p(rs),
@@ -808,6 +808,11 @@ def sumsq_det(g, partial, out):
 
 def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
+
+
+def gemv_mfma_min_rows(rows: int):
+    """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (default 3; 17 = never)."""
+    L.lib().mh_gemv_mfma_min_rows(i32(rows))
 
 
 def gemm_force_kernel(which: int):

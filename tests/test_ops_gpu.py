@@ -470,7 +470,8 @@ def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
 
 # ---- KV-cache decode kernels ---------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4096), (3, 515, 264), (5, 32003, 256), (11, 1024, 11008)])
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4096), (3, 515, 264), (5, 32003, 256), (11, 1024, 11008), (16, 4096, 4096), (4, 22016, 4096),
+                                   (13, 515, 11008), (20, 1000, 2080)])
 def test_gemv_small_m(ops, dtype, M, N, K):
     x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
     resid = rnd(M, N, dtype=dtype, seed=2)
@@ -630,7 +631,7 @@ def test_attention_fwd_lazy_rescale_with_growing_row_maxima(ops, dtype, causal):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1000, 1024), (3, 515, 272), (2, 256, 11008)])
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1000, 1024), (3, 515, 272), (2, 256, 11008), (4, 4096, 11008), (16, 12288, 4096), (13, 515, 2112)])
 def test_fp8_block_quant_and_gemv(ops, dtype, M, N, K):
     """fp8 weight path of the decode step: the quantiser must produce OCP e4m3 bytes (checked by reinterpreting them as
     torch.float8_e4m3fn) with scale = max|block| / 448, and the GEMV must equal x @ dequant(q, s)^T to fp32 accuracy; the

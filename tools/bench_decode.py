@@ -7,6 +7,9 @@ import torch
 from merlin_amd.model.llama_mmgpt import build_synthetic_model
 from merlin_amd import synth
 
+from merlin_amd import ops as _O
+if os.environ.get("MH_GEMV_MFMA_MIN"):  # A/B: 17 = never use the MFMA GEMV
+    _O.gemv_mfma_min_rows(int(os.environ["MH_GEMV_MFMA_MIN"]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 NEW = 160

@@ -210,8 +210,9 @@ int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, i
 int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* scales, int N, int K, int dt, void* stream);
 int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
                  int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream);
-/* mh_gemv / mh_gemv_fp8w take up to 16 activation rows; from `rows` rows on (default 3) they run as an MFMA kernel (16 weight rows per
- * block streamed straight into the B-operand registers, K split over 8 waves) instead of one wave per weight row.  A/B switch: */
+/* mh_gemv / mh_gemv_fp8w take up to 16 activation rows; from 6 (16-bit weights) / 5 (fp8 weights) rows on they run as an MFMA kernel
+ * (16-64 weight rows per block streamed straight into the B-operand registers, K split over 8 waves) instead of one wave per weight
+ * row.  A/B switch (sets both thresholds; 17 = never): */
 void mh_gemv_mfma_min_rows(int rows);
 /* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */

@@ -251,15 +251,22 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
 // their block's partial product is scaled once per load step.  Partial tiles of the 8 waves are summed through LDS in a fixed order.
 constexpr int GM_KC = 2048;            // activation chunk in LDS: 16 rows x (2048 + 8) x 2 B = 65.8 KB
 constexpr int GM_LD = GM_KC + 8;
-template <int DT, bool FP8W>
+// RG = 16-row groups per block (1 or 4): a block re-reads the whole activation chunk (M x K) from L2 whatever it does with it, so at
+// 16 rows per block that traffic equals the weight stream at M = 16 and the kernel is L2-bound (measured 2.9 TB/s); 64 rows per block
+// share one LDS copy and one A fragment per step between four B fragments.  Large N only: N / 64 blocks must still fill the chip.
+template <int DT, bool FP8W, int RG>
 __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ x, int64_t ldx, const void* __restrict__ Wv, int64_t ldw,
                                                    const float* __restrict__ wsc, void* __restrict__ out, int64_t ldo,
                                                    const uint16_t* __restrict__ resid, int64_t ldr, int M, int N, int K, int out_f32) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [16][GM_LD], then reused as float red[8][64][4]
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [16][GM_LD], then reused as float red[8][RG][64][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16, j = lane & 15, kq = lane >> 4;
-  const int nrow = min(n0 + j, N - 1);
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int n0 = blockIdx.x * 16 * RG, j = lane & 15, kq = lane >> 4;
+  int nrow[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) nrow[g] = min(n0 + 16 * g + j, N - 1);
+  f32x4_t acc[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nb = (K + 127) / 128;
   for (int kc = 0; kc < K; kc += GM_KC) {
     const int klen = min(GM_KC, K - kc);
@@ -272,64 +279,109 @@ __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ 
     }
     __syncthreads();
     if constexpr (!FP8W) {
-      const uint16_t* wr = (const uint16_t*)Wv + (int64_t)nrow * ldw + kc + kq * 8;
+      // steps of 32 k, wave w takes steps w, w + 8, ...; software-pipelined: the loads of the NEXT iteration are issued before the
+      // current ones are consumed (2 x U x RG x 16 B in flight per lane)
+      constexpr int U = RG == 1 ? 4 : 2;  // (RG = 2, 4: 2 x 2 x RG x 16 B in flight per lane)
+      constexpr int ITER = 8 * 32 * U;
+      const uint16_t* wr[RG];
+#pragma unroll
+      for (int g = 0; g < RG; ++g) wr[g] = (const uint16_t*)Wv + (int64_t)nrow[g] * ldw + kc + kq * 8;
       const uint16_t* xr = xs + j * GM_LD + kq * 8;
-      // steps of 32 k, wave w takes steps w, w + 8, ...; 4 loads in flight per lane
-      for (int k0 = wave * 32; k0 < klen; k0 += 8 * 32 * 4) {
-        uint4 wv[4];
+      uint4 cur[RG][U], nxt[RG][U];
+      const int kbeg = wave * 32;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = (k0 + u * 256 < klen) ? *(const uint4*)(wr + k0 + u * 256) : make_uint4(0, 0, 0, 0);
+      for (int g = 0; g < RG; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (k0 + u * 256 >= klen) break;
+        for (int u = 0; u < U; ++u) cur[g][u] = (kbeg + u * 256 < klen) ? *(const uint4*)(wr[g] + kbeg + u * 256) : make_uint4(0, 0, 0, 0);
+      for (int k0 = kbeg; k0 < klen; k0 += ITER) {
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            nxt[g][u] = (k0 + ITER + u * 256 < klen) ? *(const uint4*)(wr[g] + k0 + ITER + u * 256) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (k0 + u * 256 >= klen) continue;
           const uint4 xv = *(const uint4*)(xr + k0 + u * 256);
-          acc = mfma16<DT>(xv, wv[u], acc);
+#pragma unroll
+          for (int g = 0; g < RG; ++g) acc[g] = mfma16<DT>(xv, cur[g][u], acc[g]);
         }
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u) cur[g][u] = nxt[g][u];
       }
     } else {
-      const uint8_t* wr = (const uint8_t*)Wv + (int64_t)nrow * ldw + kc + kq * 16;   // ldw = K bytes
-      const float* sr = wsc + (int64_t)nrow * nb;
+      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...; next iteration's loads issued before the current are consumed
+      constexpr int U = RG == 1 ? 2 : 1;
+      constexpr int ITER = 8 * 64 * U;
+      const uint8_t* wr[RG];
+      const float* sr[RG];
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        wr[g] = (const uint8_t*)Wv + (int64_t)nrow[g] * ldw + kc + kq * 16;   // ldw = K bytes
+        sr[g] = wsc + (int64_t)nrow[g] * nb;
+      }
       const uint16_t* xr = xs + j * GM_LD + kq * 16;
-      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...
-      for (int k0 = wave * 64; k0 < klen; k0 += 8 * 64 * 2) {
-        uint4 qv[2];
-        float sc2[2];
+      uint4 cur[RG][U], nxt[RG][U];
+      float scur[RG][U], snxt[RG][U];
+      const int kbeg = wave * 64;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const bool ok = k0 + u * 512 < klen;
-          qv[u] = ok ? *(const uint4*)(wr + k0 + u * 512) : make_uint4(0, 0, 0, 0);
-          sc2[u] = ok ? sr[(kc + k0 + u * 512) >> 7] : 0.f;
+      for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool ok = kbeg + u * 512 < klen;
+          cur[g][u] = ok ? *(const uint4*)(wr[g] + kbeg + u * 512) : make_uint4(0, 0, 0, 0);
+          scur[g][u] = ok ? sr[g][(kc + kbeg + u * 512) >> 7] : 0.f;
         }
+      for (int k0 = kbeg; k0 < klen; k0 += ITER) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (k0 + u * 512 >= klen) break;
-          float w[16];
-          fp8x4_to_f32(qv[u].x, w); fp8x4_to_f32(qv[u].y, w + 4); fp8x4_to_f32(qv[u].z, w + 8); fp8x4_to_f32(qv[u].w, w + 12);
-          const uint4 b0 = pack8<DT>(w), b1 = pack8<DT>(w + 8);   // e4m3 values are exact in bf16 and fp16
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool ok = k0 + ITER + u * 512 < klen;
+            nxt[g][u] = ok ? *(const uint4*)(wr[g] + k0 + ITER + u * 512) : make_uint4(0, 0, 0, 0);
+            snxt[g][u] = ok ? sr[g][(kc + k0 + ITER + u * 512) >> 7] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (k0 + u * 512 >= klen) continue;
           const uint4 x0 = *(const uint4*)(xr + k0 + u * 512), x1 = *(const uint4*)(xr + k0 + u * 512 + 8);
-          f32x4_t part = {0.f, 0.f, 0.f, 0.f};
-          part = mfma16<DT>(x0, b0, part);
-          part = mfma16<DT>(x1, b1, part);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = fmaf(sc2[u], part[r], acc[r]);
+          for (int g = 0; g < RG; ++g) {
+            float w[16];
+            fp8x4_to_f32(cur[g][u].x, w); fp8x4_to_f32(cur[g][u].y, w + 4); fp8x4_to_f32(cur[g][u].z, w + 8); fp8x4_to_f32(cur[g][u].w, w + 12);
+            const uint4 b0 = pack8<DT>(w), b1 = pack8<DT>(w + 8);   // e4m3 values are exact in bf16 and fp16
+            f32x4_t part = {0.f, 0.f, 0.f, 0.f};
+            part = mfma16<DT>(x0, b0, part);
+            part = mfma16<DT>(x1, b1, part);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][r] = fmaf(scur[g][u], part[r], acc[g][r]);
+          }
         }
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u) { cur[g][u] = nxt[g][u]; scur[g][u] = snxt[g][u]; }
       }
     }
   }
   // D lane l reg r = D[m = 4 * (l >> 4) + r][n = l & 15]: sum the 8 waves' tiles in wave order
   __syncthreads();
   float* red = (float*)xs;
-  *(f32x4_t*)(red + (wave * 64 + lane) * 4) = acc;
+#pragma unroll
+  for (int g = 0; g < RG; ++g) *(f32x4_t*)(red + ((wave * RG + g) * 64 + lane) * 4) = acc[g];
   __syncthreads();
-  if (wave == 0) {
-    f32x4_t s4 = *(const f32x4_t*)(red + lane * 4);
+  if (wave < RG) {
+    const int g = wave;
+    f32x4_t s4 = *(const f32x4_t*)(red + (g * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < 8; ++w) {
-      const f32x4_t t = *(const f32x4_t*)(red + (w * 64 + lane) * 4);
+      const f32x4_t t = *(const f32x4_t*)(red + ((w * RG + g) * 64 + lane) * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s4[r] += t[r];
     }
-    const int n = n0 + j;
+    const int n = n0 + 16 * g + j;
     if (n < N) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -350,11 +402,22 @@ static int launch_gemv_mfma(const void* x, int64_t ldx, const void* W, int64_t l
   constexpr int lds = 16 * GM_LD * 2;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W>), dim3((N + 15) / 16), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
-                     (const uint16_t*)resid, ldr, M, N, K, out_f32);
+  // rows per block: as many as still give ~1.5+ blocks per CU (two 66 KB blocks fit a CU): measured, 64-row blocks win at N = 32 064
+  // (501 blocks) and lose at N = 22 016 (344 blocks: an uneven second block per CU)
+  if (N >= 30000)
+    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 4>), dim3((N + 63) / 64), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
+                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
+  else if (N >= 12000)
+    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 2>), dim3((N + 31) / 32), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
+                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
+  else
+    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 1>), dim3((N + 15) / 16), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
+                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
   MH_LAUNCH_CHECK();
 }
 
@@ -506,9 +569,13 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 
 }  // namespace
 
-static int g_gemv_mfma_min_rows = 3;
-// A/B switch for kernel development: activation-row count from which mh_gemv / mh_gemv_fp8w use the MFMA form (default 3; 17 = never)
-extern "C" void mh_gemv_mfma_min_rows(int rows) { g_gemv_mfma_min_rows = rows; }
+// activation-row count from which the MFMA form is used (measured crossovers, profiles/r02_gemv_ab.txt: 16-bit weights ~6 rows, fp8
+// weights ~5: below that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
+static int g_gemv_mfma_min_rows = 6, g_gemv_mfma_min_rows_fp8 = 5;
+extern "C" void mh_gemv_mfma_min_rows(int rows) {
+  if (rows <= 0) { g_gemv_mfma_min_rows = 6; g_gemv_mfma_min_rows_fp8 = 5; }  // restore the defaults
+  else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = rows;
+}
 
 extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
                        int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
@@ -624,7 +691,7 @@ extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const flo
   if (!x || !q || !scales || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if (M >= g_gemv_mfma_min_rows && (K % 64) == 0) {
+  if (M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }

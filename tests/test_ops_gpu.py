@@ -473,16 +473,22 @@ def test_gemm_256_tile_kernel(ops, dtype, M, N, K, which):
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4096), (3, 515, 264), (5, 32003, 256), (11, 1024, 11008), (16, 4096, 4096), (4, 22016, 4096),
                                    (13, 515, 11008), (20, 1000, 2080)])
 def test_gemv_small_m(ops, dtype, M, N, K):
+    """Both GEMV forms (one wave per weight row; MFMA with the weights streamed into the B-operand registers, 3..16 rows) at every M."""
     x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
     resid = rnd(M, N, dtype=dtype, seed=2)
     ref = x.float() @ w.float().t()
-    assert relerr(ops.gemv(x, w), ref) < 3 * EPS16[dtype]
-    assert relerr(ops.gemv(x, w, resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
-    assert relerr(ops.gemv(x, w, out_f32=True), ref) < 1e-5
-    assert torch.equal(ops.gemv(x, w), ops.gemv(x, w))
-    # against the MFMA GEMM on the same operands (the prefill path): same values up to the summation order
-    if K % 64 == 0:
-        assert relerr(ops.gemv(x, w, out_f32=True), ops.gemm_nt(x, w, out_f32=True)) < 1e-5
+    try:
+        for mn in ((3, 17) if M <= 8 else (3,)):
+            ops.gemv_mfma_min_rows(mn)
+            assert relerr(ops.gemv(x, w), ref) < 3 * EPS16[dtype]
+            assert relerr(ops.gemv(x, w, resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
+            assert relerr(ops.gemv(x, w, out_f32=True), ref) < 1e-5
+            assert torch.equal(ops.gemv(x, w), ops.gemv(x, w))
+            # against the MFMA GEMM on the same operands (the prefill path): same values up to the summation order
+            if K % 64 == 0:
+                assert relerr(ops.gemv(x, w, out_f32=True), ops.gemm_nt(x, w, out_f32=True)) < 1e-5
+    finally:
+        ops.gemv_mfma_min_rows(0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -654,10 +660,15 @@ def test_fp8_block_quant_and_gemv(ops, dtype, M, N, K):
     q_ref = (wpad * (1.0 / s_ref)[:, :, None]).view(N, nb * 128)[:, :K].to(torch.float8_e4m3fn)
     assert torch.equal(q.view(torch.float8_e4m3fn).float(), q_ref.float())
     ref = x.float() @ deq.t()
-    got = ops.gemv_fp8w(x, (q, s), out_f32=True)
-    assert relerr(got, ref) < 2e-5
     resid = rnd(M, N, dtype=dtype, seed=3)
-    assert relerr(ops.gemv_fp8w(x, (q, s), resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
+    try:
+        for mn in ((3, 17) if M <= 8 else (3,)):  # the MFMA form and the one-wave-per-row form
+            ops.gemv_mfma_min_rows(mn)
+            got = ops.gemv_fp8w(x, (q, s), out_f32=True)
+            assert relerr(got, ref) < 2e-5
+            assert relerr(ops.gemv_fp8w(x, (q, s), resid=resid), ref + resid.float()) < 3 * EPS16[dtype]
+    finally:
+        ops.gemv_mfma_min_rows(0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -144,6 +144,9 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
 /* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip,
  * else 128x128), 128 or 256 = force that tile. */
 void mh_gemm_force_kernel(int which);
+/* 256x256-tile kernels: 1 (default) = persistent launch, one block per CU looping over the output tiles with the next tile's
+ * first K-tile fetched under the epilogue; 0 = one block per tile (A-B benchmarks). */
+void mh_gemm_persistent(int on);
 
 /* out[C, R_pad] = in[R, C]^T for 16-bit elements (operand re-layout for dgrad / wgrad GEMMs);
  * columns [R, R_pad) of out are zero filled so the transposed operand's K is a multiple of 64. */

@@ -139,10 +139,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int tm, tn;
-  tile_of_block(g, tm, tn);
-  const int m0 = tm * 256, n0 = tn * (g.sw_mode == 1 ? 128 : 256);
-  const int nB1 = g.sw_mode == 1 ? g.sw_ff + n0 : n0 + 128;  // first B row of the second half-tile
+  // PERSISTENT tile loop: block b computes tiles b, b + gridDim.x, ... (grid = one block per CU, or one per tile).  The
+  // first K-tile of the next output tile is fetched while the finished one is still being written out (below).
+  const int ntiles = g.tiles_m * g.tiles_n;
   // split-K: block y of grid.y takes K-tiles [kt0, kt0 + nk) and writes its own fp32 partial tile
   const int nk_total = (g.K + BK - 1) / BK;
   const int per_split = (nk_total + g.splits - 1) / g.splits;
@@ -152,34 +151,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   // K % 64 != 0 (both operands K-strided only): rows k >= K of the last K-tile are read from a row of zeros
   const int k_tail = g.K - (nk_total - 1) * BK;  // valid rows of the global last K-tile (64 when K % 64 == 0)
 
-  // staging sources: half-tile h, instruction i: 16-byte chunk qd = i*512 + tid of the half-tile's 1024
+  // staging sources of output tile v: half-tile h, instruction i: 16-byte chunk qd = i*512 + tid of the half-tile's 1024
   const uint16_t* src[4][2];
+  int s_m0, s_n0, s_nB1;  // origin of the tile `src` points at
+  auto setup = [&](int v) {
+    int tm, tn;
+    tile_of(g, v, ntiles, tm, tn);
+    const int m0 = tm * 256, n0 = tn * (g.sw_mode == 1 ? 128 : 256);
+    const int nB1 = g.sw_mode == 1 ? g.sw_ff + n0 : n0 + 128;  // first B row of the second half-tile
+    s_m0 = m0; s_n0 = n0; s_nB1 = nB1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int qd = i * 512 + tid;
-    if constexpr (!AKS) {
-      const int row = qd >> 3, cc = qd & 7;
-      const int c = (cc ^ ((row >> 1) & 7)) * 8;
-      src[H_A0][i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c;
-      src[H_A1][i] = g.A + (int64_t)min(m0 + 128 + row, g.M - 1) * g.lda + c;
-    } else {  // [64 k][128 m]: row = k, 16 chunks per row, 32-byte chunk index swizzled by f(k)
-      const int k = qd >> 4, cc = qd & 15;
-      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
-      src[H_A0][i] = g.A + (int64_t)k * g.lda + min(m0 + col, g.M - 8);
-      src[H_A1][i] = g.A + (int64_t)k * g.lda + min(m0 + 128 + col, g.M - 8);
+    for (int i = 0; i < 2; ++i) {
+      const int qd = i * 512 + tid;
+      if constexpr (!AKS) {
+        const int row = qd >> 3, cc = qd & 7;
+        const int c = (cc ^ ((row >> 1) & 7)) * 8;
+        src[H_A0][i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c;
+        src[H_A1][i] = g.A + (int64_t)min(m0 + 128 + row, g.M - 1) * g.lda + c;
+      } else {  // [64 k][128 m]: row = k, 16 chunks per row, 32-byte chunk index swizzled by f(k)
+        const int k = qd >> 4, cc = qd & 15;
+        const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+        src[H_A0][i] = g.A + (int64_t)k * g.lda + min(m0 + col, g.M - 8);
+        src[H_A1][i] = g.A + (int64_t)k * g.lda + min(m0 + 128 + col, g.M - 8);
+      }
+      if constexpr (!BKS) {
+        const int row = qd >> 3, cc = qd & 7;
+        const int c = (cc ^ ((row >> 1) & 7)) * 8;
+        src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
+        src[H_B1][i] = g.B + (int64_t)min(nB1 + row, g.N - 1) * g.ldb + c;
+      } else {
+        const int k = qd >> 4, cc = qd & 15;
+        const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+        src[H_B0][i] = g.B + (int64_t)k * g.ldb + min(n0 + col, g.N - 8);
+        src[H_B1][i] = g.B + (int64_t)k * g.ldb + min(n0 + 128 + col, g.N - 8);
+      }
     }
-    if constexpr (!BKS) {
-      const int row = qd >> 3, cc = qd & 7;
-      const int c = (cc ^ ((row >> 1) & 7)) * 8;
-      src[H_B0][i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + c;
-      src[H_B1][i] = g.B + (int64_t)min(nB1 + row, g.N - 1) * g.ldb + c;
-    } else {
-      const int k = qd >> 4, cc = qd & 15;
-      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
-      src[H_B0][i] = g.B + (int64_t)k * g.ldb + min(n0 + col, g.N - 8);
-      src[H_B1][i] = g.B + (int64_t)k * g.ldb + min(n0 + 128 + col, g.N - 8);
-    }
-  }
+  };
   const int64_t a_kstep = AKS ? (int64_t)BK * g.lda : (int64_t)BK;  // elements per K-tile
   const int64_t b_kstep = BKS ? (int64_t)BK * g.ldb : (int64_t)BK;
   const uint16_t* zsrc = g.zero_row + lane * 8;
@@ -201,14 +208,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   };
 
   f32x4_t acc[2][4][2][2];  // [mh][i][nh][j]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
   const int swz = (frow >> 1) & 7;
@@ -229,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   u32x4 af[4][2], b0f[2][2], b1f[2][2];
 
   // fp8: per-(row, 128-k block) weight exponents (4-bit, scale 2^-e, two rows per byte) of the tile's two 128-row B groups, staged ONCE
-  // behind the operand stages: LDS [2 groups][nk][64 B].  They are the first LDS-DMA copies the block issues, so (in-order completion)
-  // they have landed whenever the first operand half-tile has.  No exponents given: the image is zero (scale 1).
+  // per output tile behind the C staging area: LDS [2 groups][nk][64 B].  They are the first LDS-DMA copies issued for a tile, so
+  // (in-order completion) they have landed whenever the first operand half-tile has.
   // The quantiser raises *sc_e_flag when any exponent is non-zero; weights whose blocks all sit within a factor 2 of their row maximum
   // (e = 0 everywhere, e.g. i.i.d. initialised weights) take the loop variant with constant block scales (wave-uniform branch).
   int esc[2][2] = {{127, 127}, {127, 127}};
@@ -239,21 +238,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
   bool use_exp = false;
   if constexpr (F8) {
     use_exp = g.sc_e && (!g.sc_e_flag || __builtin_amdgcn_readfirstlane(*g.sc_e_flag) != 0);
-    if (use_exp) {
-      char* eimg = smem + LDS256;
-      const int gp = g.sc_e_group;  // bytes per group image (multiple of 4096, >= nk * 64)
-      const int grp = wave >> 2, wq = wave & 3;
-      const uint8_t* src = g.sc_e + (int64_t)((grp ? nB1 : n0) >> 7) * gp;
-      for (int c = 0; c < gp; c += 4096) glds16(src + c + wq * 1024 + lane * 16, eimg + grp * gp + c + wq * 1024);
-      e_lane = lds0 + LDS256 + wn * 16 + (frow >> 1);
-    }
+    e_lane = lds0 + LDS256 + wn * 16 + (frow >> 1);
   }
-
-  // prologue: 6 half-tiles in consumption order; A0(0), B0(0) landed for everyone before the first read
-  issue(H_A0, 0); issue(H_B0, 0); issue(H_B1, 0); issue(H_A1, 0); issue(H_A0, 1); issue(H_B0, 1);
-  MH_WAIT_VM(8);
-  MH_BAR();
-  if (wm == 1) MH_BAR();  // the wm=1 group runs one barrier behind
+  auto load_exp = [&]() {  // exponent images of the tile `src` points at
+    if constexpr (F8) {
+      if (use_exp) {
+        char* eimg = smem + LDS256;
+        const int gp = g.sc_e_group;  // bytes per group image (multiple of 4096, >= nk * 64)
+        const int grp = wave >> 2, wq = wave & 3;
+        const uint8_t* es = g.sc_e + (int64_t)((grp ? s_nB1 : s_n0) >> 7) * gp;
+        for (int c = 0; c < gp; c += 4096) glds16(es + c + wq * 1024 + lane * 16, eimg + grp * gp + c + wq * 1024);
+      }
+    }
+  };
 
   auto k_loop = [&](auto ESC_) {
   constexpr bool ESC = decltype(ESC_)::value;
@@ -315,13 +312,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
     MH_BAR();
   }
   };
+
+  int v = blockIdx.x;
+  setup(v);
+  load_exp();
+  // prologue: 6 half-tiles in consumption order; A0(0), B0(0) landed for everyone before the first read
+  issue(H_A0, 0); issue(H_B0, 0); issue(H_B1, 0); issue(H_A1, 0); issue(H_A0, 1); issue(H_B0, 1);
+  MH_WAIT_VM(8);
+  MH_BAR();
+
+  for (;;) {
+  if (wm == 1) MH_BAR();  // the wm=1 group runs one barrier behind
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if constexpr (F8) {
     if (use_exp) k_loop(std::true_type{}); else k_loop(std::false_type{});
   } else {
     k_loop(std::false_type{});
   }
   if (wm == 0) MH_BAR();
-  MH_WAIT_VM(0);  // drain the (redundant) tail loads before the block's LDS is released
+  MH_WAIT_VM(0);  // the (redundant) tail loads have landed: no LDS-DMA write is in flight
+  const int m0 = s_m0, n0 = s_n0, nB1 = s_nB1;  // the finished tile
+  const int vn = v + gridDim.x;
+  const bool more = vn < ntiles;  // (block-uniform)
+  __syncthreads();  // every wave is done with the operand tiles in LDS
+  if (more) {
+    // the next tile's first K-tile (stage 0) is fetched under the epilogue, which stages C in [STAGE256, STAGE256 + 128 * C_ROW)
+    setup(vn);
+    load_exp();
+    issue(H_A0, 0); issue(H_B0, 0); issue(H_B1, 0); issue(H_A1, 0);
+  }
   if constexpr (F8) {  // C[m, n] = sc_m[m] * sc_n[n] * sum_k qa[m, k] qb[n, k]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -341,16 +367,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
 
   // Staged epilogue (16-bit C, vectorisable layout): the accumulator layout gives a lane 4 consecutive n of one
   // row, i.e. 32-byte pieces of 16 different rows per store instruction (measured: several microseconds per
-  // tile).  The block instead packs the whole 256x256 tile into LDS ([256 rows][528 B]: 512 B of data + 16 B pad;
-  // conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 512
-  // contiguous bytes per row.
+  // tile).  The block instead packs the tile, 128 rows at a time, into LDS ([128 rows][528 B]: 512 B of data + 16 B pad;
+  // conflict-free for the 8-byte writes and the 16-byte reads; placed in stage 1 of the operand ring, which the prefetch
+  // above does not touch) and writes it out as 16 bytes per lane = 512 contiguous bytes per row.
   if (epi_can_stage(g)) {
-    __syncthreads();  // every wave is done with the operand tiles in LDS
-    const unsigned st_w = lds0 + (unsigned)(wm * 64 + (lane & 15)) * C_ROW + (unsigned)(wn * 32 + 4 * (lane >> 4)) * 2;
-    auto fill = [&](auto EPI_) {
-      constexpr int EPI = decltype(EPI_)::value;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
+    char* cst = smem + STAGE256;
+    const unsigned st_w = (unsigned)(wm * 64 + (lane & 15)) * C_ROW + (unsigned)(wn * 32 + 4 * (lane >> 4)) * 2;
+    const int ncol = n0 + (tid & 31) * 8;
+    const bool n_ok = ncol < g.N;
+    auto half = [&](auto A_) {
+      constexpr int a = decltype(A_)::value;
+      auto fill = [&](auto EPI_) {
+        constexpr int EPI = decltype(EPI_)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = min(m0 + a * 128 + wm * 64 + i * 16 + (lane & 15), g.M - 1);
@@ -359,125 +387,151 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int n = min(n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4), g.N - 4);
-              float v[4] = {acc[a][i][b][j][0], acc[a][i][b][j][1], acc[a][i][b][j][2], acc[a][i][b][j][3]};
-              epi_xform4<DT, EPI>(g, m, n, v);
-              const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
-              *(uint2*)(smem + (st_w - lds0) + (a * 128 + i * 16) * C_ROW + (b * 128 + j * 16) * 2) = pk;
+              float v4[4] = {acc[a][i][b][j][0], acc[a][i][b][j][1], acc[a][i][b][j][2], acc[a][i][b][j][3]};
+              epi_xform4<DT, EPI>(g, m, n, v4);
+              const uint2 pk = make_uint2(pack2<DT>(v4[0], v4[1]), pack2<DT>(v4[2], v4[3]));
+              *(uint2*)(cst + st_w + (i * 16) * C_ROW + (b * 128 + j * 16) * 2) = pk;
             }
         }
-    };
-    switch (g.epi) {
-      case 0: fill(std::integral_constant<int, 0>{}); break;
-      case MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_RESIDUAL>{}); break;
-      case MH_EPI_BIAS: fill(std::integral_constant<int, MH_EPI_BIAS>{}); break;
-      case MH_EPI_BIAS | MH_EPI_QUICK_GELU: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{}); break;
-      case MH_EPI_BIAS | MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_RESIDUAL>{}); break;
-      default: break;  // excluded by epi_can_stage
-    }
-    __syncthreads();
-    const int ncol = n0 + (tid & 31) * 8;
-    const bool n_ok = ncol < g.N;
-    if (g.sw_mode == 1) {
-      // fused SwiGLU forward: LDS columns 0-127 = gate [n0, n0+128), 128-255 = up ff + [n0, n0+128) (16-bit, rounded)
-      const int c = tid & 31;
-      const int col = n0 + (c & 15) * 8;  // gate / act column of this chunk
-      if (col < g.sw_ff) {
+      };
+      switch (g.epi) {
+        case 0: fill(std::integral_constant<int, 0>{}); break;
+        case MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_RESIDUAL>{}); break;
+        case MH_EPI_BIAS: fill(std::integral_constant<int, MH_EPI_BIAS>{}); break;
+        case MH_EPI_BIAS | MH_EPI_QUICK_GELU: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{}); break;
+        case MH_EPI_BIAS | MH_EPI_RESIDUAL: fill(std::integral_constant<int, MH_EPI_BIAS | MH_EPI_RESIDUAL>{}); break;
+        default: break;  // excluded by epi_can_stage
+      }
+      __syncthreads();
+      const int mh = m0 + a * 128;  // first global row of this half
+      if (g.sw_mode == 1) {
+        // fused SwiGLU forward: LDS columns 0-127 = gate [n0, n0+128), 128-255 = up ff + [n0, n0+128) (16-bit, rounded)
+        const int c = tid & 31;
+        const int col = n0 + (c & 15) * 8;  // gate / act column of this chunk
+        if (col < g.sw_ff) {
 #pragma unroll 2
-        for (int pass = 0; pass < 16; ++pass) {
-          const int row = pass * 16 + (tid >> 5);
-          if (m0 + row >= g.M) continue;
-          const uint4 mine = *(const uint4*)(smem + row * C_ROW + c * 16);
-          uint16_t* gu = (uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc;
-          if (c < 16) {
-            *(uint4*)(gu + col) = mine;
-            float ga[8], ub[8];
-            unpack8<DT>(mine, ga);
-            unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (c + 16) * 16), ub);
+          for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 5);
+            if (mh + row >= g.M) continue;
+            const uint4 mine = *(const uint4*)(cst + row * C_ROW + c * 16);
+            uint16_t* gu = (uint16_t*)g.C + (int64_t)(mh + row) * g.ldc;
+            if (c < 16) {
+              *(uint4*)(gu + col) = mine;
+              float ga[8], ub[8];
+              unpack8<DT>(mine, ga);
+              unpack8<DT>(*(const uint4*)(cst + row * C_ROW + (c + 16) * 16), ub);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ga[k] = swiglu_fwd1(ga[k], ub[k]);
-            *(uint4*)((uint16_t*)g.sw_out + (int64_t)(m0 + row) * g.sw_ldo + col) = pack8<DT>(ga);
-          } else {
-            *(uint4*)(gu + g.sw_ff + col) = mine;
+              for (int k = 0; k < 8; ++k) ga[k] = swiglu_fwd1(ga[k], ub[k]);
+              *(uint4*)((uint16_t*)g.sw_out + (int64_t)(mh + row) * g.sw_ldo + col) = pack8<DT>(ga);
+            } else {
+              *(uint4*)(gu + g.sw_ff + col) = mine;
+            }
           }
         }
-      }
-      return;
-    }
-    if (g.sw_mode == 2) {
-      // fused SwiGLU backward: the staged tile is dact (rounded to 16 bits exactly as the unfused path stores it)
-      if (n_ok) {
+      } else if (g.sw_mode == 2) {
+        // fused SwiGLU backward: the staged tile is dact (rounded to 16 bits exactly as the unfused path stores it)
+        if (n_ok) {
 #pragma unroll 2
-        for (int pass = 0; pass < 16; ++pass) {
-          const int row = pass * 16 + (tid >> 5);
-          if (m0 + row >= g.M) continue;
-          float d_[8], ga[8], ub[8], dg[8], du[8];
-          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (tid & 31) * 16), d_);
-          const uint16_t* gu = (const uint16_t*)g.sw_in + (int64_t)(m0 + row) * g.sw_ldi;
-          unpack8<DT>(*(const uint4*)(gu + ncol), ga);
-          unpack8<DT>(*(const uint4*)(gu + g.sw_ff + ncol), ub);
+          for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 5);
+            if (mh + row >= g.M) continue;
+            float d_[8], ga[8], ub[8], dg[8], du[8];
+            unpack8<DT>(*(const uint4*)(cst + row * C_ROW + (tid & 31) * 16), d_);
+            const uint16_t* gu = (const uint16_t*)g.sw_in + (int64_t)(mh + row) * g.sw_ldi;
+            unpack8<DT>(*(const uint4*)(gu + ncol), ga);
+            unpack8<DT>(*(const uint4*)(gu + g.sw_ff + ncol), ub);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
-          uint16_t* dgu = (uint16_t*)g.sw_out + (int64_t)(m0 + row) * g.sw_ldo;
-          *(uint4*)(dgu + ncol) = pack8<DT>(dg);
-          *(uint4*)(dgu + g.sw_ff + ncol) = pack8<DT>(du);
-        }
-      }
-      return;
-    }
-    if (g.rope_tab && ncol < g.rope_cols) {
-      // fused RoPE (llama_flash_attn_monkey_patch.py:56-59): the tile holds whole heads (256 % D == 0), so the thread
-      // that owns a low-half 8-channel chunk also reads its partner chunk D/2 channels later from the same LDS row and
-      // rotates the two ROUNDED 16-bit values exactly as the stand-alone mh_rope_qk does on the stored tensor.
-      const int hc = g.rope_D >> 4;            // chunks per half head
-      const int c = tid & 31;
-      if ((c % (2 * hc)) < hc) {
-        const int j0 = (c % hc) * 8;           // first rotary pair index of this chunk
-#pragma unroll 2
-        for (int pass = 0; pass < 16; ++pass) {
-          const int row = pass * 16 + (tid >> 5);
-          if (m0 + row >= g.M) continue;
-          float lo[8], hi[8];
-          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + c * 16), lo);
-          unpack8<DT>(*(const uint4*)(smem + row * C_ROW + (c + hc) * 16), hi);
-          const float2* tb = (const float2*)g.rope_tab + (int64_t)((m0 + row) % g.rope_S) * (g.rope_D >> 1) + j0;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            rope_rot(lo[k], hi[k], tb[k].x, tb[k].y, lo[k], hi[k]);
+            for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+            uint16_t* dgu = (uint16_t*)g.sw_out + (int64_t)(mh + row) * g.sw_ldo;
+            *(uint4*)(dgu + ncol) = pack8<DT>(dg);
+            *(uint4*)(dgu + g.sw_ff + ncol) = pack8<DT>(du);
           }
-          uint16_t* dst = (uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc + ncol;
-          *(uint4*)dst = pack8<DT>(lo);
-          *(uint4*)(dst + (g.rope_D >> 1)) = pack8<DT>(hi);
         }
-      }
-      return;
-    }
+      } else if (g.rope_tab && n0 < g.rope_cols) {
+        // fused RoPE (llama_flash_attn_monkey_patch.py:56-59): the tile holds whole heads (256 % D == 0, rope_cols % D == 0), so the
+        // thread that owns a low-half 8-channel chunk also reads its partner chunk D/2 channels later from the same LDS row and
+        // rotates the two ROUNDED 16-bit values exactly as the stand-alone mh_rope_qk does on the stored tensor; chunks at or
+        // beyond rope_cols (the v heads of a tile that straddles the boundary) are copied through.
+        const int hc = g.rope_D >> 4;            // chunks per half head
+        const int c = tid & 31;
+        const bool rot = ncol < g.rope_cols;
+        if (!rot || (c % (2 * hc)) < hc) {
+          const int j0 = (c % hc) * 8;           // first rotary pair index of this chunk
+#pragma unroll 2
+          for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 5);
+            if (mh + row >= g.M) continue;
+            uint16_t* dst = (uint16_t*)g.C + (int64_t)(mh + row) * g.ldc + ncol;
+            if (!rot) {
+              if (n_ok) *(uint4*)dst = *(const uint4*)(cst + row * C_ROW + c * 16);
+              continue;
+            }
+            float lo[8], hi[8];
+            unpack8<DT>(*(const uint4*)(cst + row * C_ROW + c * 16), lo);
+            unpack8<DT>(*(const uint4*)(cst + row * C_ROW + (c + hc) * 16), hi);
+            const float2* tb = (const float2*)g.rope_tab + (int64_t)((mh + row) % g.rope_S) * (g.rope_D >> 1) + j0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              rope_rot(lo[k], hi[k], tb[k].x, tb[k].y, lo[k], hi[k]);
+            }
+            *(uint4*)dst = pack8<DT>(lo);
+            *(uint4*)(dst + (g.rope_D >> 1)) = pack8<DT>(hi);
+          }
+        }
+      } else {
 #pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
-      const int row = pass * 16 + (tid >> 5);
-      const uint4 v = *(const uint4*)(smem + row * C_ROW + (tid & 31) * 16);
-      if (n_ok && m0 + row < g.M) *(uint4*)((uint16_t*)g.C + (int64_t)(m0 + row) * g.ldc + ncol) = v;
-    }
-    return;
-  }
-  epi_dispatch<DT>(g, [&](auto store) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + a * 128 + wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
-            const f32x4_t v = acc[a][i][b][j];
-            store(m, n, v[0], v[1], v[2], v[3]);
-          }
+        for (int pass = 0; pass < 8; ++pass) {
+          const int row = pass * 16 + (tid >> 5);
+          const uint4 val = *(const uint4*)(cst + row * C_ROW + (tid & 31) * 16);
+          if (n_ok && mh + row < g.M) *(uint4*)((uint16_t*)g.C + (int64_t)(mh + row) * g.ldc + ncol) = val;
+        }
       }
-  });
+    };
+    half(std::integral_constant<int, 0>{});
+    __syncthreads();  // the first half has been read out of the staging rows
+    half(std::integral_constant<int, 1>{});
+  } else {
+    epi_dispatch<DT>(g, [&](auto store) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + a * 128 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = n0 + b * 128 + wn * 32 + j * 16 + 4 * (lane >> 4);
+              const f32x4_t val = acc[a][i][b][j];
+              store(m, n, val[0], val[1], val[2], val[3]);
+            }
+        }
+    });
+  }
+  if (!more) break;
+  v = vn;
+  MH_WAIT_VM(0);    // stage 0 of the next tile has landed (it had the whole epilogue); this tile's stores are acknowledged
+  __syncthreads();  // ... for every thread, and the staging rows (stage 1) are free again
+  issue(H_A0, 1); issue(H_B0, 1);
+  }
 }
 
 }  // namespace
+
+// Grid of a launch: one block per CU looping over the output tiles (persistent, default) or one block per tile.
+int g_persistent = 1;
+static int grid_x(const GemmArgs& g) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    ncu &= ~7;  // a multiple of the 8 XCDs: a block's tiles all map to its own XCD's run (tile_of)
+    if (ncu <= 0) ncu = 8;
+  }
+  const int ntiles = g.tiles_m * g.tiles_n;
+  return g_persistent ? min(ntiles, ncu) : ntiles;
+}
 
 template <int DT, bool AKS, bool BKS>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
@@ -486,7 +540,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt_256<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n, g.splits), dim3(512), LDS256, stream, g);
+  hipLaunchKernelGGL((gemm_nt_256<DT, AKS, BKS>), dim3(grid_x(g), g.splits), dim3(512), LDS256, stream, g);
   MH_LAUNCH_CHECK();
 }
 
@@ -514,7 +568,7 @@ int launch_f8(const GemmArgs& g, hipStream_t stream) {
     attr_set = true;
   }
   if (g.sc_e && (2 * g.sc_e_group > F8_EXP_BYTES || (g.sc_e_group & 4095) || g.sc_e_group < ((g.K * 2 + 127) / 128) * 64)) return MH_ERR_SHAPE;
-  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(g.tiles_m * g.tiles_n, 1), dim3(512), LDS256 + (g.sc_e ? 2 * g.sc_e_group : 0), stream, g);
+  hipLaunchKernelGGL((gemm_nt_256<DT, false, false, true>), dim3(grid_x(g), 1), dim3(512), LDS256 + (g.sc_e ? 2 * g.sc_e_group : 0), stream, g);
   MH_LAUNCH_CHECK();
 }
 // fp8 operands: g.A / g.B point at bytes, g.K, g.lda, g.ldb are in 2-BYTE units (K/2 etc.), dt = output type
@@ -523,3 +577,5 @@ int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream) {
 }
 
 }  // namespace mhgemm
+
+extern "C" void mh_gemm_persistent(int on) { mhgemm::g_persistent = on ? 1 : 0; }

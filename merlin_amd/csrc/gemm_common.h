@@ -38,10 +38,10 @@ struct GemmArgs {
 
 constexpr int BK = 64;
 
-// block id -> (tm, tn)
-__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tm, int& tn) {
-  const int nwg = gridDim.x, bid = blockIdx.x;  // (split-K uses gridDim.y)
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+// tile index v of `nwg` -> (tm, tn).  Consecutive v go to consecutive XCDs (block b runs on XCD b % 8), so the tiles are
+// re-numbered to give each XCD one contiguous run, visited in groups of 8 tile-rows (operand panels shared in that XCD's L2).
+__device__ __forceinline__ void tile_of(const GemmArgs& g, int v, int nwg, int& tm, int& tn) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   constexpr int GM = 8;
   const int per_group = GM * g.tiles_n;
@@ -52,6 +52,8 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tm, int& t
   tm = first_m + in_g % gsize;
   tn = in_g / gsize;
 }
+// block id -> (tm, tn): one tile per block
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tm, int& tn) { tile_of(g, blockIdx.x, gridDim.x, tm, tn); }
 
 // epilogue for 4 consecutive n of one row m (v = fp32 accumulators)
 template <int DT>

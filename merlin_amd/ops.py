@@ -811,8 +811,13 @@ def sumsq(g, out):
 
 
 def gemv_mfma_min_rows(rows: int):
-    """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (default 3; 17 = never)."""
+    """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (<= 0 restores the measured defaults; 17 = never)."""
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
+
+
+def gemm_persistent(on: bool):
+    """A/B switch: persistent launch of the 256-tile GEMM kernels (default on)."""
+    L.lib().mh_gemm_persistent(i32(1 if on else 0))
 
 
 def gemm_force_kernel(which: int):

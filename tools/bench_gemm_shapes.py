@@ -9,6 +9,8 @@ import torch
 
 from merlin_amd import ops as O
 
+if "--no-persistent" in sys.argv:
+    O.gemm_persistent(False)
 dev = torch.device("cuda:0")
 T, d, ff, V = 32768, 4096, 11008, 32064
 dt = torch.bfloat16

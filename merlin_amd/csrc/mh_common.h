@@ -158,12 +158,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
 // XCD-aware 1-D grid for (batch*head, chunk) work: block b runs on XCD b%8 (observed dispatch rule, used for
 // speed only).  All `nchunk` blocks of one (b,h) are given to ONE XCD, consecutively, so the K/V (or Q/dO)
 // panels they share stay in that XCD's private L2.  Grid = round_up(BH, 8) * nchunk; returns false for the
-// padding blocks.  chunk order is the dispatch order within the (b,h).
+// padding blocks.  chunk order is the dispatch order within the (b,h) (causal kernels put their longest chunk first).
+// The LAST `XCD_TAIL` (b,h) of every XCD are dispatched chunk-major instead (chunk 0 of each of them, then chunk 1, ...):
+// causal chunks differ up to 32:1 in length, and a long chunk that starts when the queue is nearly empty leaves the
+// other CUs of the XCD idle for most of its run.
+#ifndef MH_XCD_TAIL
+#define MH_XCD_TAIL 4
+#endif
+constexpr int XCD_TAIL = MH_XCD_TAIL;
 __device__ __forceinline__ bool xcd_work(int BH, int nchunk, int& bh, int& chunk) {
   const int id = blockIdx.x;
   const int xcd = id & 7, idx = id >> 3;
-  bh = (idx / nchunk) * 8 + xcd;
-  chunk = idx % nchunk;
+  const int nb = (int)(gridDim.x >> 3) / nchunk;  // (b,h) per XCD
+  const int tail = nb < XCD_TAIL ? nb : XCD_TAIL;
+  const int head_blocks = (nb - tail) * nchunk;
+  int bl;
+  if (idx < head_blocks) {
+    bl = idx / nchunk;
+    chunk = idx % nchunk;
+  } else {
+    const int r = idx - head_blocks;
+    chunk = r / tail;
+    bl = (nb - tail) + r % tail;
+  }
+  bh = bl * 8 + xcd;
   return bh < BH;
 }
 static inline int xcd_grid(int BH, int nchunk) { return ((BH + 7) / 8) * 8 * nchunk; }

@@ -44,6 +44,8 @@ def lib() -> C.CDLL:
         _lib.mh_strerror.argtypes = [C.c_int]
         if hasattr(_lib, "mh_attn_bwd_ws_elems"):  # dev library only
             _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
+        if os.environ.get("MH_GEMM_PERSISTENT") == "0":  # A/B switch for benchmarks
+            _lib.mh_gemm_persistent(C.c_int(0))
     return _lib
 
 

@@ -816,7 +816,7 @@ def gemv_mfma_min_rows(rows: int):
 
 
 def gemm_persistent(on: bool):
-    """A/B switch: persistent launch of the 256-tile GEMM kernels (default on)."""
+    """A/B switch: persistent launch of the 256-tile GEMM kernels (default on; env MH_GEMM_PERSISTENT=0 turns it off at import)."""
     L.lib().mh_gemm_persistent(i32(1 if on else 0))
 
 

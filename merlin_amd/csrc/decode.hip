@@ -30,13 +30,20 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
 // LDS (MM x 4096 x 2 B = 64 KiB at MM = 8) and every wave reads it from there: without it each wave re-fetches all
 // activations through L1/L2 (8x the weight bytes at MM = 8; measured 1.9 TB/s of weights instead of 5).
 constexpr int GEMV_KC = 2048;  // 32 KiB at MM = 8: four blocks (16 waves) per CU keep enough weight loads in flight
-template <int DT, int MM, int ROWS, bool LDSX>
+// NSTEP 512-element steps of every weight row are requested before any is consumed: 2 when the launch has many waves per CU,
+// 8 for the N = 4096 projections (o, down: 2048 waves on 256 CUs - one short-lived wave per SIMD slot, whose run time is the
+// number of DEPENDENT memory round trips it makes, so the whole K = 4096 row is fetched in one).
+template <int DT, int MM, int ROWS, bool LDSX, int NSTEP>
 __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
                                               int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
-                                              int64_t ldr, int N, int K, int out_f32) {
+                                              int64_t ldr, int N, int K, int out_f32, int swi_ff) {
   extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [MM][GEMV_KC] when LDSX
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  // swi_ff > 0 (fused SwiGLU of the gate|up projection, W = [2 ff, K], N = ff outputs): the wave's rows are ROWS/2 gate rows n and
+  // the matching up rows ff + n, and it writes act[n] = silu(gate) * up of the ROUNDED 16-bit gate / up values (= mh_swiglu_fwd on
+  // the stored projection)
+  const int NR = swi_ff > 0 ? ROWS / 2 : ROWS;  // output columns per wave
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
   float acc[ROWS][MM];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
@@ -44,9 +51,12 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
     for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
   const uint16_t* wrow[ROWS];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (int64_t)min(n0 + r, N - 1) * ldw;
+  for (int r = 0; r < ROWS; ++r) {
+    const int wr_ = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
+    wrow[r] = W + (int64_t)wr_ * ldw;
+  }
   for (int kc = 0; kc < K; kc += GEMV_KC) {
-    const int klen = min(GEMV_KC, K - kc);
+    const int klen = LDSX ? min(GEMV_KC, K - kc) : K;  // (without LDS staging the K loop is not chunked)
     if constexpr (LDSX) {
       if (kc) __syncthreads();
       for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
@@ -56,18 +66,17 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
       __syncthreads();
     }
     if (n0 < N) {
-      // two 512-element steps per iteration: 2 x ROWS weight loads in flight per lane before any is consumed
-      for (int k0 = lane * 8; k0 < klen; k0 += 1024) {
-        uint4 wv[2][ROWS];
-        const bool two = k0 + 512 < klen;
+      for (int k0 = lane * 8; k0 < klen; k0 += 512 * NSTEP) {
+        uint4 wv[NSTEP][ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) wv[0][r] = *(const uint4*)(wrow[r] + kc + k0);
+        for (int h2 = 0; h2 < NSTEP; ++h2)
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) wv[1][r] = two ? *(const uint4*)(wrow[r] + kc + k0 + 512) : make_uint4(0, 0, 0, 0);
+          for (int r = 0; r < ROWS; ++r)
+            wv[h2][r] = (k0 + h2 * 512 < klen) ? *(const uint4*)(wrow[r] + kc + k0 + h2 * 512) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+        for (int h2 = 0; h2 < NSTEP; ++h2) {
           const int kk = k0 + h2 * 512;
-          if (h2 == 1 && !two) break;
+          if (kk >= klen) break;
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
             uint4 xv;
@@ -86,12 +95,26 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
         }
       }
     }
+    if constexpr (!LDSX) break;
   }
   if (n0 >= N) return;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+  if (lane == 0 && swi_ff > 0) {
+#pragma unroll
+    for (int r = 0; r < ROWS / 2; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const float g_ = ld16<DT>((uint16_t)st16<DT>(acc[r][m])), u_ = ld16<DT>((uint16_t)st16<DT>(acc[r + ROWS / 2][m]));
+        ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(swiglu_fwd1(g_, u_));
+      }
+    }
+    return;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -489,21 +512,30 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
   float q8[8];
   unpack8<DT>(*(const uint4*)(q + (int64_t)b * ldq + (int64_t)h * D + kpart * 8), q8);
   float mx = -1e30f;
-  for (int j0 = 0; j0 < len; j0 += KPI) {
-    const int j = j0 + ksub;
-    float s = 0.f;
-    if (j < len) {
-      float kv[8];
-      unpack8<DT>(*(const uint4*)(kc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + kpart * 8), kv);
+  // (UNR key rows requested per thread before any is used: the cache is streamed, so what limits the rate is bytes in flight)
+  constexpr int UNR = 4;
+  for (int j0 = 0; j0 < len; j0 += KPI * UNR) {
+    uint4 kraw[UNR];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(q8[e], kv[e], s);
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * KPI + ksub;
+      kraw[u] = (j < len) ? *(const uint4*)(kc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + kpart * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int o2 = OCT1 / 2; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
-    s *= scale_log2;
-    if (j < len) {
-      if (kpart == 0) sc[j] = s;
-      mx = fmaxf(mx, s);
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * KPI + ksub;
+      float kv[8];
+      unpack8<DT>(kraw[u], kv);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(q8[e], kv[e], s);
+#pragma unroll
+      for (int o2 = OCT1 / 2; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
+      s *= scale_log2;
+      if (j < len) {
+        if (kpart == 0) sc[j] = s;
+        mx = fmaxf(mx, s);
+      }
     }
   }
   mx = wave_max(mx);
@@ -527,12 +559,23 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
   float o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  for (int j = gsl; j < len; j += G) {
-    const float pj = sc[j];
-    float vv[8];
-    unpack8<DT>(*(const uint4*)(vc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + c * 8), vv);
+  for (int j0 = gsl; j0 < len; j0 += G * UNR) {
+    uint4 vraw[UNR];
+    float pj[UNR];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vv[e], o[e]);
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * G;
+      const bool ok = j < len;
+      vraw[u] = ok ? *(const uint4*)(vc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + c * 8) : make_uint4(0, 0, 0, 0);
+      pj[u] = ok ? sc[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float vv[8];
+      unpack8<DT>(vraw[u], vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(pj[u], vv[e], o[e]);
+    }
   }
   __syncthreads();  // everyone is done reading the scores: reuse the buffer for the slice partials
   float* part = sc;  // [G][D]
@@ -572,53 +615,76 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 // activation-row count from which the MFMA form is used (measured crossovers, profiles/r02_gemv_ab.txt: 16-bit weights ~6 rows, fp8
 // weights ~5: below that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
 static int g_gemv_mfma_min_rows = 6, g_gemv_mfma_min_rows_fp8 = 5;
+static int g_gemv_deep = 1;  // 1-2 rows, N <= 8192: 8 instead of 2 weight steps in flight (A-B switch: mh_gemv_deep)
+extern "C" void mh_gemv_deep(int on) { g_gemv_deep = on ? 1 : 0; }
 extern "C" void mh_gemv_mfma_min_rows(int rows) {
   if (rows <= 0) { g_gemv_mfma_min_rows = 6; g_gemv_mfma_min_rows_fp8 = 5; }  // restore the defaults
   else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = rows;
 }
 
-extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
-                       int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
+                     int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, void* stream) {
   if (!x || !W || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if (M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
+  if (!swi_ff && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
   if (M > 8) return MH_ERR_ARG;
   // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
   // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
-  const int rows = M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1));
-  const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
+  // (fused SwiGLU: a wave's rows are gate/up PAIRS, so an even count; N counts outputs = pairs)
+  const int rows = swi_ff ? (M < 3 ? 2 : 4) : (M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1)));
+  const bool deep = g_gemv_deep && !swi_ff && N <= 8192;
+  const int cols = swi_ff ? rows / 2 : rows;  // output columns per wave
+  const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
-#define GO(DT_, MM_, R_, L_)                                                                                                      \
+#define GO(DT_, MM_, R_, L_, NS_)                                                                                                 \
   do {                                                                                                                             \
     const size_t lds_ = L_ ? (size_t)MM_ * GEMV_KC * 2 : 0;                                                                        \
     static bool attr_ = false;                                                                                                     \
     if (L_ && !attr_) {                                                                                                            \
-      hipFuncSetAttribute((const void*)gemv_k<DT_, MM_, R_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);           \
+      hipFuncSetAttribute((const void*)gemv_k<DT_, MM_, R_, L_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);      \
       attr_ = true;                                                                                                                \
     }                                                                                                                              \
-    hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
-                       (const uint16_t*)resid, ldr, N, K, out_f32);                                                               \
+    hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_, NS_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
+                       (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff);                                                               \
   } while (0)
 #define GOR(DT_, MM_)                                                                  \
   do {                                                                                 \
-    if (rows == 4) GO(DT_, MM_, 4, true); else if (rows == 2) GO(DT_, MM_, 2, true); else GO(DT_, MM_, 1, true); \
+    if (rows == 4) GO(DT_, MM_, 4, true, 2); else if (rows == 2) GO(DT_, MM_, 2, true, 2); else GO(DT_, MM_, 1, true, 2); \
+  } while (0)
+#define GOS(DT_, MM_)  /* 1-2 activation rows, no LDS staging: deep weight prefetch when the launch has few waves */ \
+  do {                                                                                 \
+    if (deep) GO(DT_, MM_, 2, false, 8); else GO(DT_, MM_, 2, false, 2);              \
   } while (0)
 #define GOM(DT_)                                                                                                       \
   switch (M) {                                                                                                         \
-    case 1: GO(DT_, 1, 2, false); break; case 2: GO(DT_, 2, 2, false); break; case 3: GOR(DT_, 3); break;             \
+    case 1: GOS(DT_, 1); break; case 2: GOS(DT_, 2); break; case 3: GOR(DT_, 3); break;                               \
     case 4: GOR(DT_, 4); break; case 5: GOR(DT_, 5); break; case 6: GOR(DT_, 6); break;                               \
     case 7: GOR(DT_, 7); break; default: GOR(DT_, 8); break;                                                           \
   }
   if (dt == MH_BF16) { GOM(MH_BF16); } else { GOM(MH_F16); }
 #undef GOM
+#undef GOS
 #undef GOR
 #undef GO
   MH_LAUNCH_CHECK();
 }
+
+extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
+                       int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+  return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, stream);
+}
+// act[M, ff] = silu(x Wg^T) * (x Wu^T) with Wgu = [Wg; Wu] [2 ff, K] (HF LlamaMLP gate / up of the decode step): one launch, the
+// gate|up projection never reaches memory (gate / up are rounded to 16 bits before the activation, as the two launches do).  M <= 8 rows.
+extern "C" int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* act, int64_t ldo, int M, int ff, int K, int dt,
+                              void* stream) {
+  if (ff <= 0 || M > 8) return MH_ERR_ARG;
+  return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, stream);
+}
+
 
 extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B,
                                      int H, int D, int Smax, int dt, void* stream) {

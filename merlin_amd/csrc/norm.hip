@@ -45,6 +45,54 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_k(const uint16_t* __restrict_
   }
 }
 
+// A few rows only (the decode step: 1-16 tokens): one wave per row leaves the row's 8 KB to 64 lanes in eight dependent round
+// trips.  Here a BLOCK takes a row - every thread requests its (up to four) 16-byte chunks at once - and the block-wide sum is
+// formed in a fixed order (wave sums, then waves 0..3), so the result is deterministic; it may differ from rmsnorm_fwd_k's by the
+// rounding of the sum.
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_row_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                         uint16_t* __restrict__ y, float* __restrict__ rstd_out, int d, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const uint4* xr = (const uint4*)(x + (int64_t)row * d);
+  const uint4* wr = (const uint4*)w;
+  uint4* yr = (uint4*)(y + (int64_t)row * d);
+  const int nch = d >> 3;  // <= 1024 (checked by the launcher)
+  uint4 xv[4], wv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    xv[i] = c < nch ? xr[c] : make_uint4(0, 0, 0, 0);
+    wv[i] = c < nch ? wr[c] : make_uint4(0, 0, 0, 0);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float f[8];
+    unpack8<DT>(xv[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  ss = (red[0] + red[1]) + (red[2] + red[3]);
+  const float r = rsqrtf(ss / (float)d + eps);
+  if (rstd_out && tid == 0) rstd_out[row] = r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      float f[8], g[8];
+      unpack8<DT>(xv[i], f);
+      unpack8<DT>(wv[i], g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = f[e] * r * g[e];
+      yr[c] = pack8<DT>(f);
+    }
+  }
+}
+
 // RMSNorm forward that also emits the row-quantised e4m3 copy of its (16-bit rounded) output + the row scale: the operand of the
 // fp8 GEMM that follows, without a separate pass over y (BASELINE cfg 5: quantisation fused into the norm).  Bit-identical to
 // rmsnorm_fwd_k followed by quant_fp8_rows_k.  x and w are re-read from L1/L2 (a row is 8 KB), y and q are written once.
@@ -362,6 +410,16 @@ extern "C" int mh_norm_bwd_partials(int rows) { return partials_for(rows); }
 extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int d, float eps, int dt,
                               void* stream) {
   if (!x || !w || !y || rows <= 0 || d <= 0 || (d & 7)) return MH_ERR_ARG;
+  if (rows <= 64 && d <= 8192 && aligned16(x) && aligned16(w) && aligned16(y)) {  // a few rows (decode): a block per row
+    if (dt == MH_BF16)
+      hipLaunchKernelGGL(rmsnorm_fwd_row_k<MH_BF16>, dim3(rows), dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w,
+                         (uint16_t*)y, rstd, d, eps);
+    else if (dt == MH_F16)
+      hipLaunchKernelGGL(rmsnorm_fwd_row_k<MH_F16>, dim3(rows), dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w,
+                         (uint16_t*)y, rstd, d, eps);
+    else return MH_ERR_DTYPE;
+    MH_LAUNCH_CHECK();
+  }
   const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   if (dt == MH_BF16)
     hipLaunchKernelGGL(rmsnorm_fwd_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,

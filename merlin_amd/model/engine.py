@@ -925,7 +925,7 @@ class HipEngine:
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv(o, W.wo, resid=x)
             h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-            act = O.swiglu_fwd(O.gemv(h2, W.wgu))
+            act = O.gemv_swiglu(h2, W.wgu)
             x = O.gemv(act, W.wd, resid=x2)
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
         Vpad = _ru(V, 64)

@@ -143,6 +143,20 @@ def gemv(x, w, out=None, resid=None, out_f32=False, n=None):
     return out
 
 
+def gemv_swiglu(x, wgu, out=None):
+    """act[M, ff] = silu(x @ Wg^T) * (x @ Wu^T), wgu = [Wg; Wu] [2 ff, K]: the decode step's gate|up projection + SwiGLU in one launch
+    (gate / up rounded to 16 bits first, as gemv + swiglu_fwd).  More than 8 rows: the two launches."""
+    M, K = x.shape
+    ff = wgu.shape[0] // 2
+    assert wgu.shape[1] == K and x.dtype == wgu.dtype
+    if M > 8:
+        return swiglu_fwd(gemv(x, wgu), out=out)
+    out = torch.empty(M, ff, dtype=x.dtype, device=x.device) if out is None else out
+    L.check(L.lib().mh_gemv_swiglu(p(x), i64(_rowmajor(x)), p(wgu), i64(_rowmajor(wgu)), p(out), i64(_rowmajor(out)), i32(M), i32(ff), i32(K),
+                                   i32(dt_of(x)), _stream()), "mh_gemv_swiglu")
+    return out
+
+
 def quant_fp8_b128(w):
     """w [N, K] (16-bit) -> (q uint8 [N, K] OCP e4m3, scales fp32 [N, ceil(K/128)])."""
     N, K = w.shape
@@ -813,6 +827,11 @@ def sumsq(g, out):
 def gemv_mfma_min_rows(rows: int):
     """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (<= 0 restores the measured defaults; 17 = never)."""
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
+
+
+def gemv_deep(on: bool):
+    """A/B switch: deep weight prefetch of the 1-2 row GEMV at N <= 8192 (default on)."""
+    L.lib().mh_gemv_deep(i32(1 if on else 0))
 
 
 def gemm_persistent(on: bool):

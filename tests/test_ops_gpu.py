@@ -492,6 +492,37 @@ def test_gemv_small_m(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,ff,K", [(1, 11008, 4096), (2, 520, 264), (3, 1000, 4096), (5, 11008, 4096), (8, 136, 2048), (11, 256, 512)])
+def test_gemv_swiglu_fused(ops, dtype, M, ff, K):
+    """Decode-step gate|up projection + SwiGLU in one launch = the two launches (gate / up rounded to 16 bits before the activation;
+    the activation itself may round differently in the last bit), and HF LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) in fp32."""
+    x, wgu = rnd(M, K, dtype=dtype), rnd(2 * ff, K, dtype=dtype, seed=1, scale=0.1)
+    one = ops.gemv_swiglu(x, wgu)
+    if M <= 8:
+        try:
+            ops.gemv_mfma_min_rows(17)  # the reference pair on the same (row-per-wave) GEMV form
+            two = ops.swiglu_fwd(ops.gemv(x, wgu))
+        finally:
+            ops.gemv_mfma_min_rows(0)
+        assert float((one != two).float().mean()) < 1e-3 and relerr(one, two) < EPS16[dtype]
+    gu = (x.float() @ wgu.float().t()).to(dtype).float()  # the projection as the reference stores it
+    ref = torch.nn.functional.silu(gu[:, :ff]) * gu[:, ff:]
+    assert relerr(one, ref) < 4 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(1, 4096), (3, 1024), (16, 4096), (5, 8192), (64, 264)])
+def test_rmsnorm_few_rows(ops, dtype, rows, d):
+    """The block-per-row RMSNorm the decode step uses (<= 64 rows) against torch fp32 (HF LlamaRMSNorm)."""
+    x, w = rnd(rows, d, dtype=dtype), rnd(d, dtype=dtype, seed=1)
+    y = ops.rmsnorm_fwd(x, w, 1e-6)
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()
+    assert relerr(y, ref) < 2 * EPS16[dtype]
+    assert torch.equal(y, ops.rmsnorm_fwd(x, w, 1e-6))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,D,Smax,lens", [(2, 2, 128, 40, [17, 40]), (3, 4, 64, 700, [1, 333, 700]), (1, 32, 128, 4200, [4100])])
 def test_decode_rope_append_and_attention(ops, dtype, B, H, D, Smax, lens):
     """One decode step against a torch fp32 restatement of HF LlamaAttention with a KV cache: rotate-half RoPE at each

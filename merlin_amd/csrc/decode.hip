@@ -30,9 +30,8 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
 // LDS (MM x 4096 x 2 B = 64 KiB at MM = 8) and every wave reads it from there: without it each wave re-fetches all
 // activations through L1/L2 (8x the weight bytes at MM = 8; measured 1.9 TB/s of weights instead of 5).
 constexpr int GEMV_KC = 2048;  // 32 KiB at MM = 8: four blocks (16 waves) per CU keep enough weight loads in flight
-// NSTEP 512-element steps of every weight row are requested before any is consumed: 2 when the launch has many waves per CU,
-// 8 for the N = 4096 projections (o, down: 2048 waves on 256 CUs - one short-lived wave per SIMD slot, whose run time is the
-// number of DEPENDENT memory round trips it makes, so the whole K = 4096 row is fetched in one).
+// NSTEP 512-element steps of every weight row are requested before any is consumed (2; 8 measured the same at N = 4096, where a
+// launch is 2048 short-lived waves: profiles/r02_decode_bench.txt).
 template <int DT, int MM, int ROWS, bool LDSX, int NSTEP>
 __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
                                               int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
@@ -595,17 +594,30 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
   }
 }
 
+// (splits <= 32: every partial is requested before any is used - the kernel is a handful of dependent L2 round trips otherwise)
 template <int DT, int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restrict__ ws, uint16_t* __restrict__ out, int H, int splits) {
+  __shared__ float sm[32], sl[32];
   const int bh = blockIdx.x, tid = threadIdx.x;
   const float* w = ws + (int64_t)bh * splits * (D + 2);
+  float v[32];
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) v[s2] = s2 < splits ? w[s2 * (D + 2) + tid] : 0.f;
+  if (tid < splits) {
+    sm[tid] = w[tid * (D + 2) + D];
+    sl[tid] = w[tid * (D + 2) + D + 1];
+  }
+  __syncthreads();
   float M = -1e30f;
-  for (int s2 = 0; s2 < splits; ++s2) M = fmaxf(M, w[s2 * (D + 2) + D]);
+  for (int s2 = 0; s2 < splits; ++s2) M = fmaxf(M, sm[s2]);
   float num = 0.f, den = 0.f;
-  for (int s2 = 0; s2 < splits; ++s2) {
-    const float f = fast_exp2(w[s2 * (D + 2) + D] - M);
-    num += w[s2 * (D + 2) + tid] * f;
-    den += w[s2 * (D + 2) + D + 1] * f;
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) {
+    if (s2 < splits) {
+      const float f = fast_exp2(sm[s2] - M);
+      num += v[s2] * f;
+      den += sl[s2] * f;
+    }
   }
   out[(int64_t)bh * D + tid] = (uint16_t)st16<DT>(den > 0.f ? num / den : 0.f);
 }
@@ -615,8 +627,6 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 // activation-row count from which the MFMA form is used (measured crossovers, profiles/r02_gemv_ab.txt: 16-bit weights ~6 rows, fp8
 // weights ~5: below that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
 static int g_gemv_mfma_min_rows = 6, g_gemv_mfma_min_rows_fp8 = 5;
-static int g_gemv_deep = 1;  // 1-2 rows, N <= 8192: 8 instead of 2 weight steps in flight (A-B switch: mh_gemv_deep)
-extern "C" void mh_gemv_deep(int on) { g_gemv_deep = on ? 1 : 0; }
 extern "C" void mh_gemv_mfma_min_rows(int rows) {
   if (rows <= 0) { g_gemv_mfma_min_rows = 6; g_gemv_mfma_min_rows_fp8 = 5; }  // restore the defaults
   else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = rows;
@@ -636,7 +646,6 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
   // (fused SwiGLU: a wave's rows are gate/up PAIRS, so an even count; N counts outputs = pairs)
   const int rows = swi_ff ? (M < 3 ? 2 : 4) : (M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1)));
-  const bool deep = g_gemv_deep && !swi_ff && N <= 8192;
   const int cols = swi_ff ? rows / 2 : rows;  // output columns per wave
   const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
@@ -655,10 +664,7 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   do {                                                                                 \
     if (rows == 4) GO(DT_, MM_, 4, true, 2); else if (rows == 2) GO(DT_, MM_, 2, true, 2); else GO(DT_, MM_, 1, true, 2); \
   } while (0)
-#define GOS(DT_, MM_)  /* 1-2 activation rows, no LDS staging: deep weight prefetch when the launch has few waves */ \
-  do {                                                                                 \
-    if (deep) GO(DT_, MM_, 2, false, 8); else GO(DT_, MM_, 2, false, 2);              \
-  } while (0)
+#define GOS(DT_, MM_) GO(DT_, MM_, 2, false, 2) /* 1-2 activation rows: no LDS staging */
 #define GOM(DT_)                                                                                                       \
   switch (M) {                                                                                                         \
     case 1: GOS(DT_, 1); break; case 2: GOS(DT_, 2); break; case 3: GOR(DT_, 3); break;                               \

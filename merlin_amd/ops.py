@@ -829,11 +829,6 @@ def gemv_mfma_min_rows(rows: int):
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
 
 
-def gemv_deep(on: bool):
-    """A/B switch: deep weight prefetch of the 1-2 row GEMV at N <= 8192 (default on)."""
-    L.lib().mh_gemv_deep(i32(1 if on else 0))
-
-
 def gemm_persistent(on: bool):
     """A/B switch: persistent launch of the 256-tile GEMM kernels (default on; env MH_GEMM_PERSISTENT=0 turns it off at import)."""
     L.lib().mh_gemm_persistent(i32(1 if on else 0))

@@ -222,6 +222,11 @@ void mh_gemv_mfma_min_rows(int rows);
  * activation exactly as mh_gemv + mh_swiglu_fwd do (same result up to the last bit of the activation).  M <= 8. */
 int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* act, int64_t ldo, int M, int ff, int K, int dt,
                    void* stream);
+/* Decode step: the RMSNorm in front of the q|k|v or gate|up projection folded into the projection's launch (HF LlamaDecoderLayer,
+ * modeling_llama.py input_layernorm / post_attention_layernorm): out[M, N] = rmsnorm(x; norm_w, eps) W^T; with ff > 0, W = [Wg; Wu] and
+ * out[M, ff] = silu(gate) * up as mh_gemv_swiglu.  Every block normalises the rows itself (no separate norm kernel).  M <= 8, K <= 8192. */
+int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* out, int64_t ldo, int M, int N,
+                 int K, int ff, int dt, void* stream);
 /* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */
 int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,

@@ -32,11 +32,17 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
 constexpr int GEMV_KC = 2048;  // 32 KiB at MM = 8: four blocks (16 waves) per CU keep enough weight loads in flight
 // NSTEP 512-element steps of every weight row are requested before any is consumed (2; 8 measured the same at N = 4096, where a
 // launch is 2048 short-lived waves: profiles/r02_decode_bench.txt).
-template <int DT, int MM, int ROWS, bool LDSX, int NSTEP>
+// NORM: x is the input of the RMSNorm that precedes the projection (HF LlamaRMSNorm, weight norm_w): every block normalises the MM
+// rows itself (8 KB each, L2-resident) into LDS - same chunk assignment, summation order and rounding as rmsnorm_fwd_row_k, so the
+// result equals the two launches bit for bit - instead of a separate kernel per norm (65 per decode step).
+template <int DT, int MM, int ROWS, bool LDSX, int NSTEP, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
                                               int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
-                                              int64_t ldr, int N, int K, int out_f32, int swi_ff) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [MM][GEMV_KC] when LDSX
+                                              int64_t ldr, int N, int K, int out_f32, int swi_ff, const uint16_t* __restrict__ norm_w,
+                                              float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [MM][GEMV_KC] when LDSX, [MM][K] when NORM
+  __shared__ float red[NORM ? MM : 1][4];
+  const int xstride = NORM ? K : GEMV_KC;
   const int lane = threadIdx.x & 63;
   // swi_ff > 0 (fused SwiGLU of the gate|up projection, W = [2 ff, K], N = ff outputs): the wave's rows are ROWS/2 gate rows n and
   // the matching up rows ff + n, and it writes act[n] = silu(gate) * up of the ROUNDED 16-bit gate / up values (= mh_swiglu_fwd on
@@ -55,8 +61,49 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
     wrow[r] = W + (int64_t)wr_ * ldw;
   }
   for (int kc = 0; kc < K; kc += GEMV_KC) {
-    const int klen = LDSX ? min(GEMV_KC, K - kc) : K;  // (without LDS staging the K loop is not chunked)
-    if constexpr (LDSX) {
+    const int klen = (LDSX && !NORM) ? min(GEMV_KC, K - kc) : K;  // (without LDS staging, or with the whole row staged, the K loop is not chunked)
+    if constexpr (NORM) {
+      const int tid = threadIdx.x, nch = K >> 3;  // nch <= 1024 (launcher)
+      uint4 xv[MM][4];
+      float ssq[MM];
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        ssq[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = tid + i * 256;
+          xv[m][i] = c < nch ? *(const uint4*)(x + (int64_t)m * ldx + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[8];
+          unpack8<DT>(xv[m][i], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq[m] += f[e] * f[e];
+        }
+        ssq[m] = wave_sum(ssq[m]);
+        if (lane == 0) red[m][tid >> 6] = ssq[m];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+          float g[8];
+          unpack8<DT>(*(const uint4*)(norm_w + c * 8), g);
+#pragma unroll
+          for (int m = 0; m < MM; ++m) {
+            const float r = rsqrtf(((red[m][0] + red[m][1]) + (red[m][2] + red[m][3])) / (float)K + eps);
+            float f[8];
+            unpack8<DT>(xv[m][i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * r * g[e];
+            *(uint4*)(xs + m * K + c * 8) = pack8<DT>(f);
+          }
+        }
+      }
+      __syncthreads();
+    } else if constexpr (LDSX) {
       if (kc) __syncthreads();
       for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
         const int m = i / klen, k = i - m * klen;
@@ -79,7 +126,7 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
             uint4 xv;
-            if constexpr (LDSX) xv = *(const uint4*)(xs + m * GEMV_KC + kk);
+            if constexpr (LDSX || NORM) xv = *(const uint4*)(xs + m * xstride + kk);
             else xv = *(const uint4*)(x + (int64_t)m * ldx + kc + kk);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
@@ -94,7 +141,7 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
         }
       }
     }
-    if constexpr (!LDSX) break;
+    if constexpr (!LDSX || NORM) break;
   }
   if (n0 >= N) return;
 #pragma unroll
@@ -633,11 +680,12 @@ extern "C" void mh_gemv_mfma_min_rows(int rows) {
 }
 
 static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
-                     int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, void* stream) {
+                     int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, void* stream) {
   if (!x || !W || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if (!swi_ff && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
+  if (norm_w && (M > 8 || K > 8192 || !aligned16(norm_w))) return MH_ERR_ARG;  // fused RMSNorm: row-per-wave form, whole row in LDS
+  if (!swi_ff && !norm_w && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
@@ -649,16 +697,21 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   const int cols = swi_ff ? rows / 2 : rows;  // output columns per wave
   const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
-#define GO(DT_, MM_, R_, L_, NS_)                                                                                                 \
+#define GO1(DT_, MM_, R_, L_, NS_, NRM_, LDS_)                                                                                     \
   do {                                                                                                                             \
-    const size_t lds_ = L_ ? (size_t)MM_ * GEMV_KC * 2 : 0;                                                                        \
+    const size_t lds_ = (LDS_);                                                                                                    \
     static bool attr_ = false;                                                                                                     \
-    if (L_ && !attr_) {                                                                                                            \
-      hipFuncSetAttribute((const void*)gemv_k<DT_, MM_, R_, L_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);      \
+    if (lds_ && !attr_) {                                                                                                          \
+      hipFuncSetAttribute((const void*)gemv_k<DT_, MM_, R_, L_, NS_, NRM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MM_ * 8192 * 2)); \
       attr_ = true;                                                                                                                \
     }                                                                                                                              \
-    hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_, NS_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
-                       (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff);                                                               \
+    hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_, NS_, NRM_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
+                       (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps);                          \
+  } while (0)
+#define GO(DT_, MM_, R_, L_, NS_)                                                                                                  \
+  do {                                                                                                                             \
+    if (norm_w) GO1(DT_, MM_, R_, true, NS_, true, (size_t)MM_ * K * 2);                                                           \
+    else GO1(DT_, MM_, R_, L_, NS_, false, L_ ? (size_t)MM_ * GEMV_KC * 2 : 0);                                                    \
   } while (0)
 #define GOR(DT_, MM_)                                                                  \
   do {                                                                                 \
@@ -676,19 +729,28 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
 #undef GOS
 #undef GOR
 #undef GO
+#undef GO1
   MH_LAUNCH_CHECK();
 }
 
 extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
                        int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
-  return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, stream);
+  return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, stream);
 }
 // act[M, ff] = silu(x Wg^T) * (x Wu^T) with Wgu = [Wg; Wu] [2 ff, K] (HF LlamaMLP gate / up of the decode step): one launch, the
 // gate|up projection never reaches memory (gate / up are rounded to 16 bits before the activation, as the two launches do).  M <= 8 rows.
 extern "C" int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* act, int64_t ldo, int M, int ff, int K, int dt,
                               void* stream) {
   if (ff <= 0 || M > 8) return MH_ERR_ARG;
-  return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, stream);
+  return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, nullptr, 0.f, stream);
+}
+// The same two projections with the RMSNorm that precedes them (HF LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm ->
+// gate|up) applied by the GEMV blocks themselves: y = rmsnorm(x; norm_w, eps) W^T, and (ff > 0) act = silu(.) * (.) of the gate|up rows.
+// Equal to mh_rmsnorm_fwd + mh_gemv (+ mh_swiglu_fwd) bit for bit in the projection.  M <= 8, K <= 8192.
+extern "C" int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* out, int64_t ldo, int M, int N,
+                            int K, int ff, int dt, void* stream) {
+  if (!norm_w || M > 8 || ff < 0) return MH_ERR_ARG;
+  return gemv_impl(x, ldx, W, ldw, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, stream);
 }
 
 

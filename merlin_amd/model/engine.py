@@ -919,13 +919,11 @@ class HipEngine:
         pos = cache.lens
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
-            h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-            qkv = O.gemv(h1, W.wqkv)
+            qkv = O.gemv_norm(x, W.ln1, eps, W.wqkv)          # input_layernorm inside the projection's launch
             O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv(o, W.wo, resid=x)
-            h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-            act = O.gemv_swiglu(h2, W.wgu)
+            act = O.gemv_norm(x2, W.ln2, eps, W.wgu, swiglu=True)  # post_attention_layernorm + gate|up + SwiGLU: one launch
             x = O.gemv(act, W.wd, resid=x2)
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
         Vpad = _ru(V, 64)

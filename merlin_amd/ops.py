@@ -157,6 +157,26 @@ def gemv_swiglu(x, wgu, out=None):
     return out
 
 
+FUSED_NORM_MAX_ROWS = 2
+
+
+def gemv_norm(x, norm_w, eps, w, swiglu=False, out=None):
+    """rmsnorm(x; norm_w, eps) @ w^T with the norm done inside the projection's launch (decode step); swiglu=True: w = [Wg; Wu] and the
+    result is silu(gate) * up [M, ff].  The fused form pays for 1-2 rows (every block re-normalises the rows: measured slower than the
+    separate norm from 4 rows on); otherwise, or with K > 8192: the separate launches."""
+    M, K = x.shape
+    if M > FUSED_NORM_MAX_ROWS or K > 8192:
+        h = rmsnorm_fwd(x, norm_w, eps)
+        return gemv_swiglu(h, w, out=out) if swiglu else gemv(h, w, out=out)
+    N = w.shape[0]
+    ff = N // 2 if swiglu else 0
+    assert w.shape[1] == K and x.dtype == w.dtype == norm_w.dtype and x.is_contiguous()
+    out = torch.empty(M, ff if swiglu else N, dtype=x.dtype, device=x.device) if out is None else out
+    L.check(L.lib().mh_gemv_norm(p(x), i64(_rowmajor(x)), p(norm_w), f32(eps), p(w), i64(_rowmajor(w)), p(out), i64(_rowmajor(out)), i32(M), i32(N),
+                                 i32(K), i32(ff), i32(dt_of(x)), _stream()), "mh_gemv_norm")
+    return out
+
+
 def quant_fp8_b128(w):
     """w [N, K] (16-bit) -> (q uint8 [N, K] OCP e4m3, scales fp32 [N, ceil(K/128)])."""
     N, K = w.shape

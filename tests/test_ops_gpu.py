@@ -511,6 +511,29 @@ def test_gemv_swiglu_fused(ops, dtype, M, ff, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (2, 528, 264), (4, 22016, 4096), (5, 1008, 1024), (8, 4096, 4096), (12, 256, 512)])
+def test_gemv_with_fused_rmsnorm(ops, dtype, M, N, K):
+    """input_layernorm / post_attention_layernorm folded into the projection launch of the decode step = rmsnorm_fwd + gemv bit for bit
+    (+ swiglu within the activation's last bit), and the fp32 torch expression within 16-bit rounding."""
+    x, g, w = rnd(M, K, dtype=dtype), rnd(K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, seed=1, scale=0.1)
+    h = ops.rmsnorm_fwd(x, g, 1e-6)
+    keep = ops.FUSED_NORM_MAX_ROWS
+    try:
+        ops.FUSED_NORM_MAX_ROWS = 8  # exercise the fused kernel at every row count it supports
+        if M <= 8:
+            ops.gemv_mfma_min_rows(17)
+            assert torch.equal(ops.gemv_norm(x, g, 1e-6, w), ops.gemv(h, w))
+            one, two = ops.gemv_norm(x, g, 1e-6, w, swiglu=True), ops.swiglu_fwd(ops.gemv(h, w))
+            assert float((one != two).float().mean()) < 1e-3 and relerr(one, two) < EPS16[dtype]
+        xf = x.float()
+        hn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * g.float()).to(dtype).float()
+        assert relerr(ops.gemv_norm(x, g, 1e-6, w), hn @ w.float().t()) < 4 * EPS16[dtype]
+    finally:
+        ops.gemv_mfma_min_rows(0)
+        ops.FUSED_NORM_MAX_ROWS = keep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,d", [(1, 4096), (3, 1024), (16, 4096), (5, 8192), (64, 264)])
 def test_rmsnorm_few_rows(ops, dtype, rows, d):
     """The block-per-row RMSNorm the decode step uses (<= 64 rows) against torch fp32 (HF LlamaRMSNorm)."""

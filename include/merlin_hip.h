@@ -227,6 +227,9 @@ int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, voi
  * out[M, ff] = silu(gate) * up as mh_gemv_swiglu.  Every block normalises the rows itself (no separate norm kernel).  M <= 8, K <= 8192. */
 int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* out, int64_t ldo, int M, int N,
                  int K, int ff, int dt, void* stream);
+/* The same with fp8 (OCP e4m3, one fp32 scale per 128 k: mh_quant_fp8_b128) weights; norm_w == NULL: no norm (x is used as it is). */
+int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* q, const float* scales, void* out, int64_t ldo,
+                      int M, int N, int K, int ff, int dt, void* stream);
 /* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */
 int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,

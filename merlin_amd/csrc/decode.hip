@@ -26,6 +26,53 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
   else return __builtin_amdgcn_fdot2(__builtin_bit_cast(mh_h2, a), __builtin_bit_cast(mh_h2, b), c, false);
 }
 
+// RMSNorm of MM rows (<= 8192 wide) into LDS xs[MM][K] by one 256-thread block: the chunk assignment, summation order and rounding of
+// rmsnorm_fwd_row_k (norm.hip), so a projection fed from here equals rmsnorm + projection bit for bit.
+template <int DT, int MM>
+__device__ __forceinline__ void stage_rmsnorm(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ norm_w, float eps, int K,
+                                              uint16_t* xs, float (*red)[4]) {
+  const int tid = threadIdx.x, lane = tid & 63, nch = K >> 3;  // nch <= 1024 (launcher)
+  uint4 xv[MM][4];
+  float ssq[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    ssq[m] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      xv[m][i] = c < nch ? *(const uint4*)(x + (int64_t)m * ldx + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[8];
+      unpack8<DT>(xv[m][i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ssq[m] += f[e] * f[e];
+    }
+    ssq[m] = wave_sum(ssq[m]);
+    if (lane == 0) red[m][tid >> 6] = ssq[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      float g[8];
+      unpack8<DT>(*(const uint4*)(norm_w + c * 8), g);
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const float r = rsqrtf(((red[m][0] + red[m][1]) + (red[m][2] + red[m][3])) / (float)K + eps);
+        float f[8];
+        unpack8<DT>(xv[m][i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * r * g[e];
+        *(uint4*)(xs + m * K + c * 8) = pack8<DT>(f);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ROWS weight rows per wave, 4 waves per block.  LDSX: the block first stages a K-chunk of the MM activation rows in
 // LDS (MM x 4096 x 2 B = 64 KiB at MM = 8) and every wave reads it from there: without it each wave re-fetches all
 // activations through L1/L2 (8x the weight bytes at MM = 8; measured 1.9 TB/s of weights instead of 5).
@@ -63,46 +110,7 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   for (int kc = 0; kc < K; kc += GEMV_KC) {
     const int klen = (LDSX && !NORM) ? min(GEMV_KC, K - kc) : K;  // (without LDS staging, or with the whole row staged, the K loop is not chunked)
     if constexpr (NORM) {
-      const int tid = threadIdx.x, nch = K >> 3;  // nch <= 1024 (launcher)
-      uint4 xv[MM][4];
-      float ssq[MM];
-#pragma unroll
-      for (int m = 0; m < MM; ++m) {
-        ssq[m] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = tid + i * 256;
-          xv[m][i] = c < nch ? *(const uint4*)(x + (int64_t)m * ldx + c * 8) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f[8];
-          unpack8<DT>(xv[m][i], f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ssq[m] += f[e] * f[e];
-        }
-        ssq[m] = wave_sum(ssq[m]);
-        if (lane == 0) red[m][tid >> 6] = ssq[m];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256;
-        if (c < nch) {
-          float g[8];
-          unpack8<DT>(*(const uint4*)(norm_w + c * 8), g);
-#pragma unroll
-          for (int m = 0; m < MM; ++m) {
-            const float r = rsqrtf(((red[m][0] + red[m][1]) + (red[m][2] + red[m][3])) / (float)K + eps);
-            float f[8];
-            unpack8<DT>(xv[m][i], f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = f[e] * r * g[e];
-            *(uint4*)(xs + m * K + c * 8) = pack8<DT>(f);
-          }
-        }
-      }
-      __syncthreads();
+      stage_rmsnorm<DT, MM>(x, ldx, norm_w, eps, K, xs, red);
     } else if constexpr (LDSX) {
       if (kc) __syncthreads();
       for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
@@ -217,13 +225,18 @@ __device__ __forceinline__ void fp8x4_to_f32(uint32_t p, float* f) {
 
 // y[m, n] = sum_kb s[n, kb] * sum_{k in block} q[n, k] x[m, k] (+ resid): one wave per weight row, 16 fp8 (16 B) per lane
 // and step (a lane's 16 values lie inside one 128-block), fp32 accumulate.  K % 16 == 0.
-template <int DT, int MM, int ROWS, bool LDSX>
+// (NORM / swi_ff: the fused RMSNorm and SwiGLU of gemv_k, same semantics)
+template <int DT, int MM, int ROWS, bool LDSX, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ q,
                                                    const float* __restrict__ sc, void* __restrict__ out, int64_t ldo,
-                                                   const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs8[];  // [MM][GEMV_KC] when LDSX (as in gemv_k)
+                                                   const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32, int swi_ff,
+                                                   const uint16_t* __restrict__ norm_w, float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs8[];  // [MM][GEMV_KC] when LDSX (as in gemv_k), [MM][K] when NORM
+  __shared__ float red[NORM ? MM : 1][4];
+  const int xstride = NORM ? K : GEMV_KC;
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  const int NR = swi_ff > 0 ? ROWS / 2 : ROWS;  // output columns per wave
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
   const int nb = (K + 127) / 128;
   float acc[ROWS][MM];
 #pragma unroll
@@ -234,13 +247,15 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
   const float* srow[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    const int n = min(n0 + r, N - 1);
+    const int n = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
     qrow[r] = q + (int64_t)n * K;
     srow[r] = sc + (int64_t)n * nb;
   }
   for (int kc = 0; kc < K; kc += GEMV_KC) {
-    const int klen = min(GEMV_KC, K - kc);
-    if constexpr (LDSX) {
+    const int klen = NORM ? K : min(GEMV_KC, K - kc);
+    if constexpr (NORM) {
+      stage_rmsnorm<DT, MM>(x, ldx, norm_w, eps, K, xs8, red);
+    } else if constexpr (LDSX) {
       if (kc) __syncthreads();
       for (int i = threadIdx.x * 8; i < MM * klen; i += 256 * 8) {
         const int m = i / klen, k = i - m * klen;
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
             float xa[8];
-            if constexpr (LDSX) unpack8<DT>(*(const uint4*)(xs8 + m * GEMV_KC + k0 + 8 * hlf), xa);
+            if constexpr (LDSX || NORM) unpack8<DT>(*(const uint4*)(xs8 + m * xstride + k0 + 8 * hlf), xa);
             else unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + kc + k0 + 8 * hlf), xa);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
@@ -287,12 +302,26 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
           for (int m = 0; m < MM; ++m) acc[r][m] = fmaf(s[r], p[r][m], acc[r][m]);
       }
     }
+    if constexpr (NORM) break;
   }
   if (n0 >= N) return;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+  if (lane == 0 && swi_ff > 0) {
+#pragma unroll
+    for (int r = 0; r < ROWS / 2; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const float g_ = ld16<DT>((uint16_t)st16<DT>(acc[r][m])), u_ = ld16<DT>((uint16_t)st16<DT>(acc[r + ROWS / 2][m]));
+        ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(swiglu_fwd1(g_, u_));
+      }
+    }
+    return;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -820,43 +849,68 @@ extern "C" int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* sca
   MH_LAUNCH_CHECK();
 }
 
-extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
-                            int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
+                          int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, void* stream) {
   if (!x || !q || !scales || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if (M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
+  if ((norm_w || swi_ff) && (M > 8 || K > 8192 || (norm_w && !aligned16(norm_w)))) return MH_ERR_ARG;
+  if (!norm_w && !swi_ff && M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
   if (M > 8) return MH_ERR_ARG;
-  const int rows = M < 3 ? 1 : (N >= 8192 ? 2 : 1);  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv)
-  const dim3 grid((N + 4 * rows - 1) / (4 * rows)), block(256);
+  const int rows = swi_ff ? 2 : (M < 3 ? 1 : (N >= 8192 ? 2 : 1));  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv); SwiGLU: one gate/up pair
+  const int cols = swi_ff ? rows / 2 : rows;
+  const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
-#define GO(DT_, MM_, R_, L_)                                                                                                       \
+#define GO1(DT_, MM_, R_, L_, NRM_, LDS_)                                                                                           \
   do {                                                                                                                              \
-    const size_t lds_ = L_ ? (size_t)MM_ * GEMV_KC * 2 : 0;                                                                         \
+    const size_t lds_ = (LDS_);                                                                                                     \
     static bool attr_ = false;                                                                                                      \
-    if (L_ && !attr_) {                                                                                                             \
-      hipFuncSetAttribute((const void*)gemv_fp8w_k<DT_, MM_, R_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);       \
+    if (lds_ && !attr_) {                                                                                                           \
+      hipFuncSetAttribute((const void*)gemv_fp8w_k<DT_, MM_, R_, L_, NRM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MM_ * 8192 * 2)); \
       attr_ = true;                                                                                                                 \
     }                                                                                                                               \
-    hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_, R_, L_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, \
-                       out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);                                                      \
+    hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_, R_, L_, NRM_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, \
+                       out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps);                \
+  } while (0)
+#define GO(DT_, MM_, R_, L_)                                                                                                       \
+  do {                                                                                                                              \
+    if (norm_w) GO1(DT_, MM_, R_, true, true, (size_t)MM_ * K * 2);                                                                 \
+    else GO1(DT_, MM_, R_, L_, false, L_ ? (size_t)MM_ * GEMV_KC * 2 : 0);                                                          \
   } while (0)
 #define GOR(DT_, MM_)                                                                        \
   do {                                                                                       \
     if (rows == 2) GO(DT_, MM_, 2, true); else GO(DT_, MM_, 1, true);                       \
   } while (0)
+#define GOS(DT_, MM_)                                                                        \
+  do {                                                                                       \
+    if (rows == 2) GO(DT_, MM_, 2, false); else GO(DT_, MM_, 1, false);                     \
+  } while (0)
 #define GOM(DT_)                                                                                                   \
   switch (M) {                                                                                                     \
-    case 1: GO(DT_, 1, 1, false); break; case 2: GO(DT_, 2, 1, false); break; case 3: GOR(DT_, 3); break;         \
+    case 1: GOS(DT_, 1); break; case 2: GOS(DT_, 2); break; case 3: GOR(DT_, 3); break;                           \
     case 4: GOR(DT_, 4); break; case 5: GOR(DT_, 5); break; case 6: GOR(DT_, 6); break;                           \
     case 7: GOR(DT_, 7); break; default: GOR(DT_, 8); break;                                                       \
   }
   if (dt == MH_BF16) { GOM(MH_BF16); } else { GOM(MH_F16); }
 #undef GOM
+#undef GOS
 #undef GOR
 #undef GO
+#undef GO1
   MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
+                            int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
+  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, stream);
+}
+// mh_gemv_norm with fp8 (e4m3, per-128-block scales) weights: out = rmsnorm(x; norm_w, eps) W^T (norm_w may be NULL: no norm), ff > 0: SwiGLU of the
+// gate|up rows.  M <= 8, K <= 8192.
+extern "C" int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* q, const float* scales, void* out,
+                                 int64_t ldo, int M, int N, int K, int ff, int dt, void* stream) {
+  if (M > 8 || ff < 0) return MH_ERR_ARG;
+  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, stream);
 }

@@ -944,13 +944,11 @@ class HipEngine:
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
             Q = F8["layers"][li]
-            h1 = O.rmsnorm_fwd(x, W.ln1, eps)
-            qkv = O.gemv_fp8w(h1, Q["wqkv"])
+            qkv = O.gemv_fp8w_norm(x, W.ln1, eps, Q["wqkv"])
             O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv_fp8w(o, Q["wo"], resid=x)
-            h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-            act = O.swiglu_fwd(O.gemv_fp8w(h2, Q["wgu"]))
+            act = O.gemv_fp8w_norm(x2, W.ln2, eps, Q["wgu"], swiglu=True)
             x = O.gemv_fp8w(act, Q["wd"], resid=x2)
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
         logits = O.gemv_fp8w(hn, F8["lm_head"], out_f32=True)

@@ -167,7 +167,7 @@ def gemv_norm(x, norm_w, eps, w, swiglu=False, out=None):
     M, K = x.shape
     if M > FUSED_NORM_MAX_ROWS or K > 8192:
         h = rmsnorm_fwd(x, norm_w, eps)
-        return gemv_swiglu(h, w, out=out) if swiglu else gemv(h, w, out=out)
+        return gemv_swiglu(h, w, out=out) if swiglu else gemv(h, w, out=out)  # (gemv_swiglu: fused up to 8 rows)
     N = w.shape[0]
     ff = N // 2 if swiglu else 0
     assert w.shape[1] == K and x.dtype == w.dtype == norm_w.dtype and x.is_contiguous()
@@ -201,6 +201,28 @@ def gemv_fp8w(x, qw, out=None, resid=None, out_f32=False, n=None):
         L.check(L.lib().mh_gemv_fp8w(p(xs), i64(_rowmajor(xs)), p(q), p(sc), p(os_), i64(_rowmajor(os_)), p(rs),
                                      i64(_rowmajor(rs) if rs is not None else 0), i32(mm), i32(N), i32(K), i32(dt_of(x)),
                                      i32(int(out.dtype == torch.float32)), _stream()), "mh_gemv_fp8w")
+    return out
+
+
+def gemv_fp8w_norm(x, norm_w, eps, qw, swiglu=False, out=None):
+    """gemv_norm with fp8 weights (qw = (q, scales) from quant_fp8_b128).  1-2 rows: norm, projection (and SwiGLU) in one launch;
+    3-8 rows: separate norm, SwiGLU still fused; more rows: separate launches."""
+    q, sc = qw
+    M, K = x.shape
+    N = q.shape[0]
+    ff = N // 2 if swiglu else 0
+    if M > 8 or K > 8192:
+        y = gemv_fp8w(rmsnorm_fwd(x, norm_w, eps), qw)
+        return swiglu_fwd(y, out=out) if swiglu else y
+    fuse_norm = M <= FUSED_NORM_MAX_ROWS
+    if not fuse_norm:
+        x = rmsnorm_fwd(x, norm_w, eps)
+        if not swiglu:
+            return gemv_fp8w(x, qw, out=out)
+    assert q.shape[1] == K and x.is_contiguous()
+    out = torch.empty(M, ff if swiglu else N, dtype=x.dtype, device=x.device) if out is None else out
+    L.check(L.lib().mh_gemv_fp8w_norm(p(x), i64(_rowmajor(x)), p(norm_w if fuse_norm else None), f32(eps), p(q), p(sc), p(out), i64(_rowmajor(out)),
+                                      i32(M), i32(N), i32(K), i32(ff), i32(dt_of(x)), _stream()), "mh_gemv_fp8w_norm")
     return out
 
 

@@ -534,6 +534,28 @@ def test_gemv_with_fused_rmsnorm(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (2, 528, 512), (4, 22016, 4096), (8, 1024, 2048), (11, 256, 512)])
+def test_gemv_fp8w_with_fused_rmsnorm_and_swiglu(ops, dtype, M, N, K):
+    """fp8-weight decode projections with the RMSNorm (1-2 rows) and SwiGLU (up to 8 rows) folded in = the separate launches."""
+    x, g, w = rnd(M, K, dtype=dtype), rnd(K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, seed=1, scale=0.1)
+    qw = ops.quant_fp8_b128(w)
+    h = ops.rmsnorm_fwd(x, g, 1e-6)
+    keep = ops.FUSED_NORM_MAX_ROWS
+    try:
+        ops.FUSED_NORM_MAX_ROWS = 8
+        if M <= 8:
+            ops.gemv_mfma_min_rows(17)
+        ref = ops.gemv_fp8w(h, qw)
+        got = ops.gemv_fp8w_norm(x, g, 1e-6, qw)
+        assert torch.equal(got, ref) if M <= 8 else relerr(got, ref) < 2 * EPS16[dtype]
+        one, two = ops.gemv_fp8w_norm(x, g, 1e-6, qw, swiglu=True), ops.swiglu_fwd(ref)
+        assert float((one != two).float().mean()) < 1e-3 and relerr(one, two) < 2 * EPS16[dtype]
+    finally:
+        ops.gemv_mfma_min_rows(0)
+        ops.FUSED_NORM_MAX_ROWS = keep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,d", [(1, 4096), (3, 1024), (16, 4096), (5, 8192), (64, 264)])
 def test_rmsnorm_few_rows(ops, dtype, rows, d):
     """The block-per-row RMSNorm the decode step uses (<= 64 rows) against torch fp32 (HF LlamaRMSNorm)."""

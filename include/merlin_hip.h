@@ -230,6 +230,13 @@ int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, float eps, cons
 /* The same with fp8 (OCP e4m3, one fp32 scale per 128 k: mh_quant_fp8_b128) weights; norm_w == NULL: no norm (x is used as it is). */
 int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* q, const float* scales, void* out, int64_t ldo,
                       int M, int N, int K, int ff, int dt, void* stream);
+/* The q|k|v projection of one decode step in ONE launch: optional input_layernorm (norm_w, may be NULL), projection with 16-bit weights W
+ * [3 H D, K] or (W == NULL) fp8 weights q8 + scales, rotate-half RoPE of q and k at pos[m] (llama_flash_attn_monkey_patch.py:56-59 on one
+ * token) and the append of k, v to kcache / vcache [M, Smax, H D] at row pos[m].  qkv [M, 3 H D] gets the rotated q, k and v.  Equal to
+ * mh_rmsnorm_fwd + mh_gemv (mh_gemv_fp8w) + mh_decode_rope_append bit for bit.  M <= 8, K <= 8192. */
+int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, const void* q8, const float* scales,
+                     void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache,
+                     int H, int D, int Smax, void* stream);
 /* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */
 int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,

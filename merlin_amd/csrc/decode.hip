@@ -26,6 +26,39 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
   else return __builtin_amdgcn_fdot2(__builtin_bit_cast(mh_h2, a), __builtin_bit_cast(mh_h2, b), c, false);
 }
 
+// Fused decode_rope_append of the q|k|v projection (tab == nullptr: off).  A wave then owns the ROTARY PAIR (c, c + D/2) of one head of
+// one section (q, k or v) instead of two consecutive rows, so lane 0 ends up with both partners of every activation row and can rotate
+// them at pos[m] (rotate-half, as rope_append_k on the stored 16-bit values) and write k / v straight into the cache rows [m, pos[m]].
+struct RopeAppend {
+  const float2* tab;   // [max_pos, D/2] (cos, sin)
+  const int32_t* pos;  // [M]
+  uint16_t *kc, *vc;   // [M, Smax, H*D]
+  int H, D, Smax;
+};
+template <int DT, int MM>
+__device__ __forceinline__ void rope_append_store(const RopeAppend& ra, int pidx, const float (&a0)[MM], const float (&a1)[MM], uint16_t* out, int64_t ldo) {
+  const int half = ra.D >> 1, per_sec = ra.H * half;
+  const int sec = pidx / per_sec, rem = pidx - sec * per_sec, h = rem / half, c = rem - h * half;
+  const int64_t HD = (int64_t)ra.H * ra.D, col = (int64_t)h * ra.D + c;
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    float lo = ld16<DT>((uint16_t)st16<DT>(a0[m])), hi = ld16<DT>((uint16_t)st16<DT>(a1[m]));  // the projection as it would be stored
+    const int p = ra.pos[m];
+    if (sec < 2) {
+      const float2 cs = ra.tab[(int64_t)p * half + c];
+      rope_rot(lo, hi, cs.x, cs.y, lo, hi);
+    }
+    const uint16_t l16 = (uint16_t)st16<DT>(lo), h16 = (uint16_t)st16<DT>(hi);
+    out[(int64_t)m * ldo + sec * HD + col] = l16;
+    out[(int64_t)m * ldo + sec * HD + col + half] = h16;
+    if (sec > 0) {
+      uint16_t* dst = (sec == 1 ? ra.kc : ra.vc) + ((int64_t)m * ra.Smax + p) * HD + col;
+      dst[0] = l16;
+      dst[half] = h16;
+    }
+  }
+}
+
 // RMSNorm of MM rows (<= 8192 wide) into LDS xs[MM][K] by one 256-thread block: the chunk assignment, summation order and rounding of
 // rmsnorm_fwd_row_k (norm.hip), so a projection fed from here equals rmsnorm + projection bit for bit.
 template <int DT, int MM>
@@ -86,7 +119,7 @@ template <int DT, int MM, int ROWS, bool LDSX, int NSTEP, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W,
                                               int64_t ldw, void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid,
                                               int64_t ldr, int N, int K, int out_f32, int swi_ff, const uint16_t* __restrict__ norm_w,
-                                              float eps) {
+                                              float eps, RopeAppend ra) {
   extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [MM][GEMV_KC] when LDSX, [MM][K] when NORM
   __shared__ float red[NORM ? MM : 1][4];
   const int xstride = NORM ? K : GEMV_KC;
@@ -104,7 +137,12 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   const uint16_t* wrow[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    const int wr_ = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
+    int wr_ = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
+    if (ROWS == 2 && ra.tab) {  // rotary pair (c, c + D/2) of pair index n0 / 2 (N = 3 H D outputs, N / 2 pairs)
+      const int half = ra.D >> 1, pidx = min(n0 >> 1, (N >> 1) - 1), per_sec = ra.H * half;
+      const int sec = pidx / per_sec, rem = pidx - sec * per_sec, h = rem / half;
+      wr_ = sec * ra.H * ra.D + h * ra.D + (rem - h * half) + r * half;
+    }
     wrow[r] = W + (int64_t)wr_ * ldw;
   }
   for (int kc = 0; kc < K; kc += GEMV_KC) {
@@ -156,6 +194,12 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+  if constexpr (ROWS == 2) {
+    if (ra.tab) {
+      if (lane == 0) rope_append_store<DT, MM>(ra, n0 >> 1, acc[0], acc[1], (uint16_t*)out, ldo);
+      return;
+    }
+  }
   if (lane == 0 && swi_ff > 0) {
 #pragma unroll
     for (int r = 0; r < ROWS / 2; ++r) {
@@ -230,7 +274,7 @@ template <int DT, int MM, int ROWS, bool LDSX, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ q,
                                                    const float* __restrict__ sc, void* __restrict__ out, int64_t ldo,
                                                    const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32, int swi_ff,
-                                                   const uint16_t* __restrict__ norm_w, float eps) {
+                                                   const uint16_t* __restrict__ norm_w, float eps, RopeAppend ra) {
   extern __shared__ __attribute__((aligned(16))) uint16_t xs8[];  // [MM][GEMV_KC] when LDSX (as in gemv_k), [MM][K] when NORM
   __shared__ float red[NORM ? MM : 1][4];
   const int xstride = NORM ? K : GEMV_KC;
@@ -247,7 +291,12 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
   const float* srow[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    const int n = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
+    int n = swi_ff > 0 ? (r < NR ? min(n0 + r, N - 1) : swi_ff + min(n0 + r - NR, N - 1)) : min(n0 + r, N - 1);
+    if (ROWS == 2 && ra.tab) {  // rotary pair (as in gemv_k)
+      const int half = ra.D >> 1, pidx = min(n0 >> 1, (N >> 1) - 1), per_sec = ra.H * half;
+      const int sec = pidx / per_sec, rem = pidx - sec * per_sec, h = rem / half;
+      n = sec * ra.H * ra.D + h * ra.D + (rem - h * half) + r * half;
+    }
     qrow[r] = q + (int64_t)n * K;
     srow[r] = sc + (int64_t)n * nb;
   }
@@ -309,6 +358,12 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+  if constexpr (ROWS == 2) {
+    if (ra.tab) {
+      if (lane == 0) rope_append_store<DT, MM>(ra, n0 >> 1, acc[0], acc[1], (uint16_t*)out, ldo);
+      return;
+    }
+  }
   if (lane == 0 && swi_ff > 0) {
 #pragma unroll
     for (int r = 0; r < ROWS / 2; ++r) {
@@ -709,12 +764,14 @@ extern "C" void mh_gemv_mfma_min_rows(int rows) {
 }
 
 static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
-                     int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, void* stream) {
+                     int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, const RopeAppend& ra,
+                     void* stream) {
   if (!x || !W || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   if (norm_w && (M > 8 || K > 8192 || !aligned16(norm_w))) return MH_ERR_ARG;  // fused RMSNorm: row-per-wave form, whole row in LDS
-  if (!swi_ff && !norm_w && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
+  if (ra.tab && (M > 8 || swi_ff || (N & 1))) return MH_ERR_ARG;
+  if (!swi_ff && !norm_w && !ra.tab && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
@@ -722,7 +779,7 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
   // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
   // (fused SwiGLU: a wave's rows are gate/up PAIRS, so an even count; N counts outputs = pairs)
-  const int rows = swi_ff ? (M < 3 ? 2 : 4) : (M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1)));
+  const int rows = ra.tab ? 2 : swi_ff ? (M < 3 ? 2 : 4) : (M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1)));
   const int cols = swi_ff ? rows / 2 : rows;  // output columns per wave
   const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
@@ -735,7 +792,7 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
       attr_ = true;                                                                                                                \
     }                                                                                                                              \
     hipLaunchKernelGGL((gemv_k<DT_, MM_, R_, L_, NS_, NRM_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, \
-                       (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps);                          \
+                       (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps, ra);                      \
   } while (0)
 #define GO(DT_, MM_, R_, L_, NS_)                                                                                                  \
   do {                                                                                                                             \
@@ -764,14 +821,14 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
 
 extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
                        int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
-  return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, stream);
+  return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, RopeAppend{}, stream);
 }
 // act[M, ff] = silu(x Wg^T) * (x Wu^T) with Wgu = [Wg; Wu] [2 ff, K] (HF LlamaMLP gate / up of the decode step): one launch, the
 // gate|up projection never reaches memory (gate / up are rounded to 16 bits before the activation, as the two launches do).  M <= 8 rows.
 extern "C" int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* act, int64_t ldo, int M, int ff, int K, int dt,
                               void* stream) {
   if (ff <= 0 || M > 8) return MH_ERR_ARG;
-  return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, nullptr, 0.f, stream);
+  return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, nullptr, 0.f, RopeAppend{}, stream);
 }
 // The same two projections with the RMSNorm that precedes them (HF LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm ->
 // gate|up) applied by the GEMV blocks themselves: y = rmsnorm(x; norm_w, eps) W^T, and (ff > 0) act = silu(.) * (.) of the gate|up rows.
@@ -779,7 +836,7 @@ extern "C" int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64
 extern "C" int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* out, int64_t ldo, int M, int N,
                             int K, int ff, int dt, void* stream) {
   if (!norm_w || M > 8 || ff < 0) return MH_ERR_ARG;
-  return gemv_impl(x, ldx, W, ldw, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, stream);
+  return gemv_impl(x, ldx, W, ldw, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, RopeAppend{}, stream);
 }
 
 
@@ -850,17 +907,19 @@ extern "C" int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* sca
 }
 
 static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
-                          int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, void* stream) {
+                          int64_t ldr, int M, int N, int K, int dt, int out_f32, int swi_ff, const void* norm_w, float eps, const RopeAppend& ra,
+                          void* stream) {
   if (!x || !q || !scales || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if ((norm_w || swi_ff) && (M > 8 || K > 8192 || (norm_w && !aligned16(norm_w)))) return MH_ERR_ARG;
-  if (!norm_w && !swi_ff && M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
+  if ((norm_w || swi_ff || ra.tab) && (M > 8 || K > 8192 || (norm_w && !aligned16(norm_w)))) return MH_ERR_ARG;
+  if (ra.tab && (swi_ff || (N & 1))) return MH_ERR_ARG;
+  if (!norm_w && !swi_ff && !ra.tab && M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
     if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
     return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
   if (M > 8) return MH_ERR_ARG;
-  const int rows = swi_ff ? 2 : (M < 3 ? 1 : (N >= 8192 ? 2 : 1));  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv); SwiGLU: one gate/up pair
+  const int rows = (swi_ff || ra.tab) ? 2 : (M < 3 ? 1 : (N >= 8192 ? 2 : 1));  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv); SwiGLU: one gate/up pair
   const int cols = swi_ff ? rows / 2 : rows;
   const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);
   hipStream_t st = as_stream(stream);
@@ -873,7 +932,7 @@ static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float
       attr_ = true;                                                                                                                 \
     }                                                                                                                               \
     hipLaunchKernelGGL((gemv_fp8w_k<DT_, MM_, R_, L_, NRM_>), grid, block, lds_, st, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, \
-                       out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps);                \
+                       out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32, swi_ff, (const uint16_t*)norm_w, eps, ra);            \
   } while (0)
 #define GO(DT_, MM_, R_, L_)                                                                                                       \
   do {                                                                                                                              \
@@ -905,12 +964,26 @@ static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float
 
 extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
                             int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream) {
-  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, stream);
+  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, RopeAppend{}, stream);
 }
 // mh_gemv_norm with fp8 (e4m3, per-128-block scales) weights: out = rmsnorm(x; norm_w, eps) W^T (norm_w may be NULL: no norm), ff > 0: SwiGLU of the
 // gate|up rows.  M <= 8, K <= 8192.
 extern "C" int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* q, const float* scales, void* out,
                                  int64_t ldo, int M, int N, int K, int ff, int dt, void* stream) {
   if (M > 8 || ff < 0) return MH_ERR_ARG;
-  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, stream);
+  return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, RopeAppend{}, stream);
+}
+
+// q|k|v projection of the decode step with everything around it in one launch: (optional) input_layernorm of x, the projection with 16-bit
+// (W) or fp8 (q8 + scales) weights, rotate-half RoPE of q and k at pos[m] and the append of k, v to the cache rows [m, pos[m]]
+// (= mh_rmsnorm_fwd + mh_gemv / mh_gemv_fp8w + mh_decode_rope_append, bit for bit).  qkv [M, 3 H D] receives the rotated q, k and v.
+extern "C" int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, const void* q8,
+                                const float* scales, void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos,
+                                void* kcache, void* vcache, int H, int D, int Smax, void* stream) {
+  if (!cos_sin || !pos || !kcache || !vcache || H <= 0 || D <= 0 || (D & 1) || Smax <= 0 || M > 8 || (!W && !(q8 && scales))) return MH_ERR_ARG;
+  RopeAppend ra;
+  ra.tab = (const float2*)cos_sin; ra.pos = pos; ra.kc = (uint16_t*)kcache; ra.vc = (uint16_t*)vcache; ra.H = H; ra.D = D; ra.Smax = Smax;
+  const int N = 3 * H * D;
+  if (W) return gemv_impl(x, ldx, W, ldw, qkv, ldo, nullptr, 0, M, N, K, dt, 0, 0, norm_w, eps, ra, stream);
+  return gemv_fp8w_impl(x, ldx, q8, scales, qkv, ldo, nullptr, 0, M, N, K, dt, 0, 0, norm_w, eps, ra, stream);
 }

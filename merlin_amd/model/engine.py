@@ -919,8 +919,8 @@ class HipEngine:
         pos = cache.lens
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
-            qkv = O.gemv_norm(x, W.ln1, eps, W.wqkv)          # input_layernorm inside the projection's launch
-            O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
+            # input_layernorm + q|k|v projection + RoPE + K/V append: one launch
+            qkv = O.gemv_qkv_rope(x, W.ln1, eps, W.wqkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv(o, W.wo, resid=x)
             act = O.gemv_norm(x2, W.ln2, eps, W.wgu, swiglu=True)  # post_attention_layernorm + gate|up + SwiGLU: one launch
@@ -944,8 +944,7 @@ class HipEngine:
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
             Q = F8["layers"][li]
-            qkv = O.gemv_fp8w_norm(x, W.ln1, eps, Q["wqkv"])
-            O.decode_rope_append(qkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
+            qkv = O.gemv_qkv_rope(x, W.ln1, eps, Q["wqkv"], self.rope, pos, cache.k[li], cache.v[li], H, D)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv_fp8w(o, Q["wo"], resid=x)
             act = O.gemv_fp8w_norm(x2, W.ln2, eps, Q["wgu"], swiglu=True)

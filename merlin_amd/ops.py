@@ -226,6 +226,27 @@ def gemv_fp8w_norm(x, norm_w, eps, qw, swiglu=False, out=None):
     return out
 
 
+def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D):
+    """Decode-step q|k|v: (input_layernorm +) projection + RoPE at pos + K/V append in one launch; w = 16-bit weight [3HD, K] or the
+    (q, scales) pair of quant_fp8_b128.  Returns qkv [M, 3HD] (q, k rotated).  More than 8 rows: the separate launches."""
+    M, K = x.shape
+    fp8 = isinstance(w, (tuple, list))
+    if M > 8 or K > 8192:
+        h = rmsnorm_fwd(x, norm_w, eps)
+        qkv = gemv_fp8w(h, w) if fp8 else gemv(h, w)
+        decode_rope_append(qkv, table, pos, kcache, vcache, H, D)
+        return qkv
+    if M > FUSED_NORM_MAX_ROWS:
+        x, norm_w = rmsnorm_fwd(x, norm_w, eps), None
+    assert x.is_contiguous() and pos.dtype == torch.int32 and kcache.is_contiguous() and vcache.is_contiguous()
+    qkv = torch.empty(M, 3 * H * D, dtype=x.dtype, device=x.device)
+    wq, sc = (w if fp8 else (None, None))
+    L.check(L.lib().mh_gemv_qkv_rope(p(x), i64(_rowmajor(x)), p(norm_w), f32(eps), p(None if fp8 else w), i64(0 if fp8 else _rowmajor(w)), p(wq), p(sc),
+                                     p(qkv), i64(_rowmajor(qkv)), i32(M), i32(K), i32(dt_of(x)), p(table), p(pos), p(kcache), p(vcache),
+                                     i32(H), i32(D), i32(kcache.shape[1]), _stream()), "mh_gemv_qkv_rope")
+    return qkv
+
+
 def decode_rope_append(qkv, table, pos, kcache, vcache, H, D):
     """qkv [B, 3*H*D] of the new tokens (rotated in place at pos[b]); k, v appended to kcache/vcache [B, Smax, H*D]."""
     B = qkv.shape[0]

@@ -556,6 +556,37 @@ def test_gemv_fp8w_with_fused_rmsnorm_and_swiglu(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,H,D,K,Smax,pos", [(1, 32, 128, 4096, 64, [17]), (2, 4, 64, 256, 40, [0, 39]), (5, 2, 128, 512, 16, [3, 0, 15, 7, 7]),
+                                              (8, 4, 128, 1024, 24, list(range(8))), (11, 2, 64, 256, 12, list(range(11)))])
+def test_qkv_projection_with_fused_norm_rope_append(ops, dtype, fp8, B, H, D, K, Smax, pos):
+    """input_layernorm + q|k|v projection + RoPE + K/V append of one decode step in one launch = the four separate launches, bit for bit
+    (qkv buffer and the touched cache rows; untouched cache rows stay as they were)."""
+    d = H * D
+    x, g, w = rnd(B, K, dtype=dtype), rnd(K, dtype=dtype, seed=3), rnd(3 * d, K, dtype=dtype, seed=1, scale=0.1)
+    wq = ops.quant_fp8_b128(w) if fp8 else w
+    tab = ops.rope_table(Smax, D, 10000.0, dev())
+    p32 = torch.tensor(pos, dtype=torch.int32, device=dev())
+    kc0, vc0 = rnd(B, Smax, d, dtype=dtype, seed=5), rnd(B, Smax, d, dtype=dtype, seed=6)
+    keep = ops.FUSED_NORM_MAX_ROWS
+    try:
+        if B <= 8:
+            ops.gemv_mfma_min_rows(17)
+        h = ops.rmsnorm_fwd(x, g, 1e-6)
+        ref = ops.gemv_fp8w(h, wq) if fp8 else ops.gemv(h, w)
+        kc1, vc1 = kc0.clone(), vc0.clone()
+        ops.decode_rope_append(ref, tab, p32, kc1, vc1, H, D)
+        for fuse_rows in (8, 0):  # norm inside the launch / separate
+            ops.FUSED_NORM_MAX_ROWS = fuse_rows
+            kc2, vc2 = kc0.clone(), vc0.clone()
+            got = ops.gemv_qkv_rope(x, g, 1e-6, wq, tab, p32, kc2, vc2, H, D)
+            assert torch.equal(got, ref) and torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    finally:
+        ops.gemv_mfma_min_rows(0)
+        ops.FUSED_NORM_MAX_ROWS = keep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,d", [(1, 4096), (3, 1024), (16, 4096), (5, 8192), (64, 264)])
 def test_rmsnorm_few_rows(ops, dtype, rows, d):
     """The block-per-row RMSNorm the decode step uses (<= 64 rows) against torch fp32 (HF LlamaRMSNorm)."""

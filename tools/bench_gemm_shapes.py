@@ -71,3 +71,11 @@ rec("wgrad down     TN [4096,11008,T]", 2 * T * d * ff, lambda: O.wgrad_tn(x, xf
 rec("wgrad lm_head  TN [32064,4096,T]", 2 * T * V * d, lambda: O.gemm_nt(dl, x, a_t=True, b_t=True, out=g5))
 layer = sum(r[1] for r in rows if "lm_head" not in r[0])
 print(f"per decoder layer: {layer:.2f} ms of GEMM -> x32 = {layer * 32:.0f} ms/step; lm_head {sum(r[1] for r in rows if 'lm_head' in r[0]):.2f} ms")
+# wgrad with a K-contiguous activation operand (a transposed copy of x written by the producer): A K-strided, B K-contiguous
+xT = x.t().contiguous()
+xfT = xf.t().contiguous()
+rec("wgrad qkv  A^T x^T-contig [12288,4096,T]", 2 * T * 3 * d * d, lambda: O.gemm_nt(dqkv, xT, a_t=True, out=g1))
+rec("wgrad gu   A^T x^T-contig [22016,4096,T]", 2 * T * 2 * ff * d, lambda: O.gemm_nt(dgu, xT, a_t=True, out=g3))
+rec("wgrad down A^T x^T-contig [4096,11008,T]", 2 * T * d * ff, lambda: O.gemm_nt(x, xfT, a_t=True, out=g4))
+dqkvT = dqkv.t().contiguous()
+rec("wgrad qkv  both contiguous NT [12288,4096,T]", 2 * T * 3 * d * d, lambda: O.gemm_nt(dqkvT, xT, out=g1))

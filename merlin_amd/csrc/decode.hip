@@ -856,8 +856,8 @@ extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int3
 }
 
 extern "C" int mh_attn_decode_splits(int B, int H, int Smax) {
-  int s = (512 + B * H - 1) / (B * H);
-  const int by_len = (Smax + 255) / 256;  // >= 256 keys per split
+  int s = (1024 + B * H - 1) / (B * H);
+  const int by_len = (Smax + 127) / 128;  // >= 128 keys per split
   if (s > by_len) s = by_len;
   if (s > 32) s = 32;
   return s < 1 ? 1 : s;

@@ -147,6 +147,9 @@ void mh_gemm_force_kernel(int which);
 /* 256x256-tile kernels: 1 (default) = persistent launch, one block per CU looping over the output tiles with the next tile's
  * first K-tile fetched under the epilogue; 0 = one block per tile (A-B benchmarks). */
 void mh_gemm_persistent(int on);
+/* Tile raster of the 256x256 / 128x128 kernels: output tiles are visited in groups of `gm` tile-rows x all tile-columns, and each XCD
+ * gets a contiguous run of the sequence (32 tiles per round = gm x 32/gm): default 4 (A-B benchmarks: 2..16). */
+void mh_gemm_raster_group(int gm);
 
 /* out[C, R_pad] = in[R, C]^T for 16-bit elements (operand re-layout for dgrad / wgrad GEMMs);
  * columns [R, R_pad) of out are zero filled so the transposed operand's K is a multiple of 64. */

@@ -44,8 +44,10 @@ def lib() -> C.CDLL:
         _lib.mh_strerror.argtypes = [C.c_int]
         if hasattr(_lib, "mh_attn_bwd_ws_elems"):  # dev library only
             _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
-        if os.environ.get("MH_GEMM_PERSISTENT") == "0":  # A/B switch for benchmarks
+        if os.environ.get("MH_GEMM_PERSISTENT") == "0":  # A/B switches for benchmarks
             _lib.mh_gemm_persistent(C.c_int(0))
+        if os.environ.get("MH_GEMM_GM"):
+            _lib.mh_gemm_raster_group(C.c_int(int(os.environ["MH_GEMM_GM"])))
     return _lib
 
 

@@ -142,11 +142,13 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
   }
 }
 
+int g_gemm_gm = 4;     // raster group height (tile rows); measured 4 < 8 < 16 on the decoder shapes (profiles/r02_gemm_raster_ab.txt)
 int g_force_kernel = 0;  // 0 auto, 128, 256 (8 waves), 4 (4 waves), 5.. (timing probes) - tests / A-B benchmarking
 
 }  // namespace
 
 extern "C" void mh_gemm_force_kernel(int which) { g_force_kernel = which; }
+extern "C" void mh_gemm_raster_group(int gm) { g_gemm_gm = gm >= 1 && gm <= 64 ? gm : 4; }
 
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
@@ -329,7 +331,7 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   g.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)C) & (f32out ? 15u : 7u)) == 0) &&
              (!(epilogue & MH_EPI_RESIDUAL) || ((ldr % 4 == 0) && ((((uintptr_t)resid) & 7u) == 0))) &&
              (!(epilogue & MH_EPI_BIAS) || ((((uintptr_t)bias) & 7u) == 0));
-  g.splits = 1; g.c_split = 0;
+  g.splits = 1; g.c_split = 0; g.gm = g_gemm_gm;
   g.rope_tab = fx.tab; g.rope_S = fx.S; g.rope_D = fx.D; g.rope_cols = fx.cols;
   g.sw_mode = fx.sw_mode; g.sw_ff = fx.sw_ff; g.sw_out = fx.sw_out; g.sw_in = fx.sw_in; g.sw_ldo = fx.sw_ldo; g.sw_ldi = fx.sw_ldi;
   g.sc_m = sa; g.sc_n = sb;
@@ -396,7 +398,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.bias = (const uint16_t*)bias; g.resid = (const uint16_t*)resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
-  g.splits = splits; g.c_split = c_split;
+  g.splits = splits; g.c_split = c_split; g.gm = g_gemm_gm;
   g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_flag = nullptr; g.sc_e_group = 0;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;

@@ -892,6 +892,11 @@ def gemv_mfma_min_rows(rows: int):
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
 
 
+def gemm_raster_group(gm: int):
+    """A/B switch: tile rows per raster group of the MFMA GEMM kernels (default 4)."""
+    L.lib().mh_gemm_raster_group(i32(gm))
+
+
 def gemm_persistent(on: bool):
     """A/B switch: persistent launch of the 256-tile GEMM kernels (default on; env MH_GEMM_PERSISTENT=0 turns it off at import)."""
     L.lib().mh_gemm_persistent(i32(1 if on else 0))

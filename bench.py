@@ -90,7 +90,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg2", "cfg3-ragged", "cfg5", "cfg5-bf16"],
                     help="cfg3 = BASELINE metric config (default); cfg3-ragged = same with ragged lengths + key padding; "
                          "cfg5 = BASELINE configs[4]: S=8192 interleave (4 images + long text), decoder GEMMs (forward, dgrad, wgrad) on the "
@@ -177,8 +177,12 @@ def main():
         opt.zero_grad()
         return out.loss
 
-    for _ in range(args.warmup):
+    for wi in range(args.warmup):
+        tw = time.perf_counter()
         loss = step()
+        if os.environ.get("MH_BENCH_PER_STEP"):  # warm-up profile (stderr): how many steps until the step time is flat
+            torch.cuda.synchronize()
+            print(f"[bench] warm-up step {wi}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

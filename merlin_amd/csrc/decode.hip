@@ -261,6 +261,18 @@ __global__ __launch_bounds__(256) void quant_fp8_b128_k(const uint16_t* __restri
   }
 }
 
+// two e4m3 values (the low or the high half of a dword) -> one packed 16-bit pair, in ONE instruction (gfx950 v_cvt_scalef32_pk_*_fp8 with
+// scale 1: e4m3 values are exact in bf16 and fp16); a dword of 4 fp8 -> 2 packed words
+template <int DT>
+__device__ __forceinline__ void fp8x4_to_pk16(uint32_t p, uint32_t& lo, uint32_t& hi) {
+  if constexpr (DT == MH_BF16) {
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(p, 1.0f, false));
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(p, 1.0f, true));
+  } else {
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(p, 1.0f, false));
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(p, 1.0f, true));
+  }
+}
 __device__ __forceinline__ void fp8x4_to_f32(uint32_t p, float* f) {
   typedef float f2_ __attribute__((ext_vector_type(2)));
   const f2_ lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, true);
@@ -327,22 +339,28 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
 #pragma unroll
           for (int m = 0; m < MM; ++m) p[r][m] = 0.f;
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {  // 8 values at a time keeps the dequantised weights of ROWS rows in 8*ROWS registers
-          float w[ROWS][8];
+        for (int hlf = 0; hlf < 2; ++hlf) {  // 8 values at a time: the weights become packed 16-bit pairs (exact) and meet the activations in
+                                             // dot2 instructions, as in gemv_k (4 cvt + 4 x MM dot2 per row instead of 4 cvt + 8 x MM fma)
+          uint32_t w[ROWS][4];
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) {
-            fp8x4_to_f32(hlf ? qv[r].z : qv[r].x, w[r]);
-            fp8x4_to_f32(hlf ? qv[r].w : qv[r].y, w[r] + 4);
+            fp8x4_to_pk16<DT>(hlf ? qv[r].z : qv[r].x, w[r][0], w[r][1]);
+            fp8x4_to_pk16<DT>(hlf ? qv[r].w : qv[r].y, w[r][2], w[r][3]);
           }
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
-            float xa[8];
-            if constexpr (LDSX || NORM) unpack8<DT>(*(const uint4*)(xs8 + m * xstride + k0 + 8 * hlf), xa);
-            else unpack8<DT>(*(const uint4*)(x + (int64_t)m * ldx + kc + k0 + 8 * hlf), xa);
+            uint4 xa;
+            if constexpr (LDSX || NORM) xa = *(const uint4*)(xs8 + m * xstride + k0 + 8 * hlf);
+            else xa = *(const uint4*)(x + (int64_t)m * ldx + kc + k0 + 8 * hlf);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) p[r][m] = fmaf(w[r][e], xa[e], p[r][m]);
+            for (int r = 0; r < ROWS; ++r) {
+              float a = p[r][m];
+              a = dot2_acc<DT>(w[r][0], xa.x, a);
+              a = dot2_acc<DT>(w[r][1], xa.y, a);
+              a = dot2_acc<DT>(w[r][2], xa.z, a);
+              a = dot2_acc<DT>(w[r][3], xa.w, a);
+              p[r][m] = a;
+            }
           }
         }
 #pragma unroll
@@ -502,9 +520,9 @@ __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ 
           const uint4 x0 = *(const uint4*)(xr + k0 + u * 512), x1 = *(const uint4*)(xr + k0 + u * 512 + 8);
 #pragma unroll
           for (int g = 0; g < RG; ++g) {
-            float w[16];
-            fp8x4_to_f32(cur[g][u].x, w); fp8x4_to_f32(cur[g][u].y, w + 4); fp8x4_to_f32(cur[g][u].z, w + 8); fp8x4_to_f32(cur[g][u].w, w + 12);
-            const uint4 b0 = pack8<DT>(w), b1 = pack8<DT>(w + 8);   // e4m3 values are exact in bf16 and fp16
+            uint4 b0, b1;  // 16 e4m3 -> 2 x 8 packed 16-bit values (exact), one convert per pair
+            fp8x4_to_pk16<DT>(cur[g][u].x, b0.x, b0.y); fp8x4_to_pk16<DT>(cur[g][u].y, b0.z, b0.w);
+            fp8x4_to_pk16<DT>(cur[g][u].z, b1.x, b1.y); fp8x4_to_pk16<DT>(cur[g][u].w, b1.z, b1.w);
             f32x4_t part = {0.f, 0.f, 0.f, 0.f};
             part = mfma16<DT>(x0, b0, part);
             part = mfma16<DT>(x1, b1, part);

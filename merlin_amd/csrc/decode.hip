@@ -450,42 +450,31 @@ __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ 
     }
     __syncthreads();
     if constexpr (!FP8W) {
-      // steps of 32 k, wave w takes steps w, w + 8, ...; software-pipelined: the loads of the NEXT iteration are issued before the
-      // current ones are consumed (2 x U x RG x 16 B in flight per lane)
-      constexpr int U = RG == 1 ? 4 : 2;  // (RG = 2, 4: 2 x 2 x RG x 16 B in flight per lane)
-      constexpr int ITER = 8 * 32 * U;
+      // steps of 32 k, wave w takes steps w, w + 8, ...: ALL of the wave's steps of this activation chunk (8; 2 x 4 at 64 rows per block:
+      // registers) are requested before the first is consumed - with 2 K of activations per chunk a wave has only a handful of steps,
+      // and taken two at a time they were that many dependent memory round trips
+      constexpr int NS = RG == 4 ? 4 : 8;
       const uint16_t* wr[RG];
 #pragma unroll
       for (int g = 0; g < RG; ++g) wr[g] = (const uint16_t*)Wv + (int64_t)nrow[g] * ldw + kc + kq * 8;
       const uint16_t* xr = xs + j * GM_LD + kq * 8;
-      uint4 cur[RG][U], nxt[RG][U];
-      const int kbeg = wave * 32;
+      for (int k0 = wave * 32; k0 < klen; k0 += 256 * NS) {
+        uint4 wv[RG][NS];
 #pragma unroll
-      for (int g = 0; g < RG; ++g)
+        for (int u = 0; u < NS; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[g][u] = (kbeg + u * 256 < klen) ? *(const uint4*)(wr[g] + kbeg + u * 256) : make_uint4(0, 0, 0, 0);
-      for (int k0 = kbeg; k0 < klen; k0 += ITER) {
+          for (int g = 0; g < RG; ++g) wv[g][u] = (k0 + u * 256 < klen) ? *(const uint4*)(wr[g] + k0 + u * 256) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < RG; ++g)
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            nxt[g][u] = (k0 + ITER + u * 256 < klen) ? *(const uint4*)(wr[g] + k0 + ITER + u * 256) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (k0 + u * 256 >= klen) continue;
+        for (int u = 0; u < NS; ++u) {
+          if (k0 + u * 256 >= klen) break;
           const uint4 xv = *(const uint4*)(xr + k0 + u * 256);
 #pragma unroll
-          for (int g = 0; g < RG; ++g) acc[g] = mfma16<DT>(xv, cur[g][u], acc[g]);
+          for (int g = 0; g < RG; ++g) acc[g] = mfma16<DT>(xv, wv[g][u], acc[g]);
         }
-#pragma unroll
-        for (int g = 0; g < RG; ++g)
-#pragma unroll
-          for (int u = 0; u < U; ++u) cur[g][u] = nxt[g][u];
       }
     } else {
-      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...; next iteration's loads issued before the current are consumed
-      constexpr int U = RG == 1 ? 2 : 1;
-      constexpr int ITER = 8 * 64 * U;
+      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...: all (4) of the chunk requested at once, as above
+      constexpr int NS = 4;
       const uint8_t* wr[RG];
       const float* sr[RG];
 #pragma unroll
@@ -494,46 +483,33 @@ __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ 
         sr[g] = wsc + (int64_t)nrow[g] * nb;
       }
       const uint16_t* xr = xs + j * GM_LD + kq * 16;
-      uint4 cur[RG][U], nxt[RG][U];
-      float scur[RG][U], snxt[RG][U];
-      const int kbeg = wave * 64;
+      for (int k0 = wave * 64; k0 < klen; k0 += 512 * NS) {
+        uint4 wv[RG][NS];
+        float sv[RG][NS];
 #pragma unroll
-      for (int g = 0; g < RG; ++g)
+        for (int u = 0; u < NS; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool ok = kbeg + u * 512 < klen;
-          cur[g][u] = ok ? *(const uint4*)(wr[g] + kbeg + u * 512) : make_uint4(0, 0, 0, 0);
-          scur[g][u] = ok ? sr[g][(kc + kbeg + u * 512) >> 7] : 0.f;
-        }
-      for (int k0 = kbeg; k0 < klen; k0 += ITER) {
-#pragma unroll
-        for (int g = 0; g < RG; ++g)
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const bool ok = k0 + ITER + u * 512 < klen;
-            nxt[g][u] = ok ? *(const uint4*)(wr[g] + k0 + ITER + u * 512) : make_uint4(0, 0, 0, 0);
-            snxt[g][u] = ok ? sr[g][(kc + k0 + ITER + u * 512) >> 7] : 0.f;
+          for (int g = 0; g < RG; ++g) {
+            const bool ok = k0 + u * 512 < klen;
+            wv[g][u] = ok ? *(const uint4*)(wr[g] + k0 + u * 512) : make_uint4(0, 0, 0, 0);
+            sv[g][u] = ok ? sr[g][(kc + k0 + u * 512) >> 7] : 0.f;
           }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (k0 + u * 512 >= klen) continue;
+        for (int u = 0; u < NS; ++u) {
+          if (k0 + u * 512 >= klen) break;
           const uint4 x0 = *(const uint4*)(xr + k0 + u * 512), x1 = *(const uint4*)(xr + k0 + u * 512 + 8);
 #pragma unroll
           for (int g = 0; g < RG; ++g) {
             uint4 b0, b1;  // 16 e4m3 -> 2 x 8 packed 16-bit values (exact), one convert per pair
-            fp8x4_to_pk16<DT>(cur[g][u].x, b0.x, b0.y); fp8x4_to_pk16<DT>(cur[g][u].y, b0.z, b0.w);
-            fp8x4_to_pk16<DT>(cur[g][u].z, b1.x, b1.y); fp8x4_to_pk16<DT>(cur[g][u].w, b1.z, b1.w);
+            fp8x4_to_pk16<DT>(wv[g][u].x, b0.x, b0.y); fp8x4_to_pk16<DT>(wv[g][u].y, b0.z, b0.w);
+            fp8x4_to_pk16<DT>(wv[g][u].z, b1.x, b1.y); fp8x4_to_pk16<DT>(wv[g][u].w, b1.z, b1.w);
             f32x4_t part = {0.f, 0.f, 0.f, 0.f};
             part = mfma16<DT>(x0, b0, part);
             part = mfma16<DT>(x1, b1, part);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][r] = fmaf(scur[g][u], part[r], acc[g][r]);
+            for (int r = 0; r < 4; ++r) acc[g][r] = fmaf(sv[g][u], part[r], acc[g][r]);
           }
         }
-#pragma unroll
-        for (int g = 0; g < RG; ++g)
-#pragma unroll
-          for (int u = 0; u < U; ++u) { cur[g][u] = nxt[g][u]; scur[g][u] = snxt[g][u]; }
       }
     }
   }

@@ -6,12 +6,17 @@
 //
 //   mh_gemv             y[m, n] = sum_k x[m, k] W[n, k] (+ resid[m, n]),  m <= 8 rows: ONE WAVE PER WEIGHT ROW, the
 //                       row is read once as 64 lanes x 16 B per step and dotted against all m activations rows
-//                       (which stay in L1/L2: m * K * 2 B <= 176 KB); fp32 accumulate, shuffle reduction.
-//   mh_decode_rope_append  rotate q, k of the new token at its own position (rotate-half, as mh_rope_qk) and append
-//                       k, v to the cache rows [b, pos[b]].
+//                       (which stay in L1/L2: m * K * 2 B <= 176 KB); fp32 accumulate, shuffle reduction.  6-16 rows: an MFMA form.
+//   mh_gemv_qkv_rope    the q|k|v projection with its neighbours in the same launch: input_layernorm of the row (every block normalises
+//                       it into LDS), rotate-half RoPE of q, k at the token's position, append of k, v to the cache - a wave owns the
+//                       rotary pair (c, c + D/2) of one head, so lane 0 ends up with both partners.
+//   mh_gemv_norm / mh_gemv_swiglu   post_attention_layernorm + gate|up projection + SwiGLU in one launch (a wave owns a gate row and
+//                       its up row); fp8-weight forms of all of these (mh_gemv_fp8w*).
+//   mh_decode_rope_append  (stand-alone form) rotate q, k of the new token at its own position and append k, v to the cache rows [b, pos[b]].
 //   mh_attn_decode      block per (b, h, key split): pass 1 D/8 lanes per key (coalesced 256-B key rows, shuffle-reduced
-//                       dot products) -> scores in LDS -> block max / sum; pass 2 lane-per-channel accumulation of
-//                       p.V (coalesced value rows); split-KV partials merged by a second kernel.  Keys [0, len[b]).
+//                       dot products, 4 rows in flight per thread) -> scores in LDS -> block max / sum; pass 2 lane-per-channel
+//                       accumulation of p.V (coalesced value rows); split-KV partials merged by a second kernel.  Keys [0, len[b]).
+// A decode step of a layer is 6 launches; each costs ~4 us of fixed time on top of its streaming, which is why the neighbours are folded in.
 #include "mh_common.h"
 
 namespace {

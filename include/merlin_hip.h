@@ -220,6 +220,8 @@ int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales,
  * (16-64 weight rows per block streamed straight into the B-operand registers, K split over 8 waves) instead of one wave per weight
  * row.  A/B switch (sets both thresholds; 17 = never): */
 void mh_gemv_mfma_min_rows(int rows);
+/* 1-2 rows, N <= 8192 (o / down projections): 1 (default) = the four waves of a block split K (4x the waves), 0 = one wave per row pair. */
+void mh_gemv_ksplit(int on);
 /* Decode-step MLP gate|up projection + SwiGLU in one launch (HF LlamaMLP, modeling_llama.py:174-176, one token per sequence):
  * act[M, ff] = silu(x Wg^T) * (x Wu^T), Wgu = [Wg; Wu] [2 ff, K] row-major; gate / up are rounded to 16 bits before the
  * activation exactly as mh_gemv + mh_swiglu_fwd do (same result up to the last bit of the activation).  M <= 8. */

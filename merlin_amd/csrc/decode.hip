@@ -234,6 +234,71 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
   }
 }
 
+// 1-2 activation rows and a SMALL N (the o / down projections: 4096 rows): one wave per ROWS weight rows gives 2048 waves for 256 CUs,
+// each streaming its rows for the whole of K - the launch is a ramp-up and a tail.  Here the four waves of a block share the same
+// ROWS rows and split K in four, i.e. four times as many waves with a quarter of the work each (all 32 wave slots of a CU busy); the
+// four partial sums meet in LDS and are added in a fixed order.
+template <int DT, int MM, int ROWS>
+__global__ __launch_bounds__(256) void gemv_ks_k(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W, int64_t ldw,
+                                                 void* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ resid, int64_t ldr, int N,
+                                                 int K, int out_f32) {
+  __shared__ float red[4][ROWS][MM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * ROWS;
+  const int kq = (((K >> 3) + 3) >> 2) << 3;  // elements per wave (a multiple of 8)
+  const int kb = wave * kq, ke = min(K, kb + kq);
+  float acc[ROWS][MM];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const uint16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (int64_t)min(n0 + r, N - 1) * ldw;
+  for (int k0 = kb + lane * 8; k0 < ke; k0 += 1024) {
+    uint4 wv[2][ROWS];
+    const bool two = k0 + 512 < ke;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wv[0][r] = *(const uint4*)(wrow[r] + k0);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wv[1][r] = two ? *(const uint4*)(wrow[r] + k0 + 512) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      if (h2 == 1 && !two) break;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const uint4 xv = *(const uint4*)(x + (int64_t)m * ldx + k0 + h2 * 512);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          float a = acc[r][m];
+          a = dot2_acc<DT>(wv[h2][r].x, xv.x, a);
+          a = dot2_acc<DT>(wv[h2][r].y, xv.y, a);
+          a = dot2_acc<DT>(wv[h2][r].z, xv.z, a);
+          a = dot2_acc<DT>(wv[h2][r].w, xv.w, a);
+          acc[r][m] = a;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const float t = wave_sum(acc[r][m]);
+      if (lane == 0) red[wave][r][m] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < ROWS * MM) {
+    const int r = threadIdx.x / MM, m = threadIdx.x % MM, n = n0 + r;
+    if (n < N) {
+      float v = (red[0][r][m] + red[1][r][m]) + (red[2][r][m] + red[3][r][m]);
+      if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+      if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+      else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+    }
+  }
+}
+
 // ---- fp8 (OCP e4m3) weights with one fp32 scale per 128 consecutive k (BASELINE cfg 5's weight format), bf16/f16
 // activations: the decode step is weight-bandwidth-bound, so halving the weight bytes is worth ~2x on the GEMVs.
 // quant: q[n, k] = fp8(w[n, k] / s[n, k/128]),  s = max|w| over the block / 448 (1 if the block is all zero).
@@ -757,6 +822,8 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 // activation-row count from which the MFMA form is used (measured crossovers, profiles/r02_gemv_ab.txt: 16-bit weights ~6 rows, fp8
 // weights ~5: below that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
 static int g_gemv_mfma_min_rows = 6, g_gemv_mfma_min_rows_fp8 = 5;
+static int g_gemv_ksplit = 1;  // 1-2 rows, N <= 8192: K split over the four waves of a block (A-B switch: mh_gemv_ksplit)
+extern "C" void mh_gemv_ksplit(int on) { g_gemv_ksplit = on ? 1 : 0; }
 extern "C" void mh_gemv_mfma_min_rows(int rows) {
   if (rows <= 0) { g_gemv_mfma_min_rows = 6; g_gemv_mfma_min_rows_fp8 = 5; }  // restore the defaults
   else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = rows;
@@ -777,6 +844,18 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   if (M > 8) return MH_ERR_ARG;
   // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
   // CU, measured at 1.4 TB/s; with 1 row per wave 3+ TB/s)
+  if (g_gemv_ksplit && M <= 2 && !swi_ff && !norm_w && !ra.tab && N <= 8192 && K >= 2048) {  // small N, 1-2 rows: K split over the block's waves
+    const dim3 gridk((N + 1) / 2), blockk(256);
+    hipStream_t stk = as_stream(stream);
+    if (dt == MH_BF16) {
+      if (M == 1) hipLaunchKernelGGL((gemv_ks_k<MH_BF16, 1, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+      else hipLaunchKernelGGL((gemv_ks_k<MH_BF16, 2, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+    } else {
+      if (M == 1) hipLaunchKernelGGL((gemv_ks_k<MH_F16, 1, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+      else hipLaunchKernelGGL((gemv_ks_k<MH_F16, 2, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint16_t*)W, ldw, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+    }
+    MH_LAUNCH_CHECK();
+  }
   // (fused SwiGLU: a wave's rows are gate/up PAIRS, so an even count; N counts outputs = pairs)
   const int rows = ra.tab ? 2 : swi_ff ? (M < 3 ? 2 : 4) : (M < 3 ? 2 : (N >= 16384 ? 4 : (N >= 8192 ? 2 : 1)));
   const int cols = swi_ff ? rows / 2 : rows;  // output columns per wave

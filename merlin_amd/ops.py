@@ -892,6 +892,11 @@ def gemv_mfma_min_rows(rows: int):
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
 
 
+def gemv_ksplit(on: bool):
+    """A/B switch: K split over a block's waves in the 1-2 row GEMV at N <= 8192 (default on)."""
+    L.lib().mh_gemv_ksplit(i32(1 if on else 0))
+
+
 def gemm_raster_group(gm: int):
     """A/B switch: tile rows per raster group of the MFMA GEMM kernels (default 4)."""
     L.lib().mh_gemm_raster_group(i32(gm))

@@ -10,6 +10,8 @@ from merlin_amd import synth
 from merlin_amd import ops as _O
 if os.environ.get("MH_GEMV_MFMA_MIN"):  # A/B: 17 = never use the MFMA GEMV
     _O.gemv_mfma_min_rows(int(os.environ["MH_GEMV_MFMA_MIN"]))
+if os.environ.get("MH_GEMV_KSPLIT"):  # A/B: 0 = one wave per row pair in the small-N GEMV
+    _O.gemv_ksplit(os.environ["MH_GEMV_KSPLIT"] != "0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 NEW = 160

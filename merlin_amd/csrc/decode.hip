@@ -483,6 +483,90 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
 
 
 // ---- 3..16 activation rows: the matrix cores do the multiplies --------------------------------------------------------------------
+// gemv_ks_k with fp8 weights: the four waves of a block share ROWS rows and split K (a multiple of 128 per wave, so a lane's 16 values
+// stay inside one scale block); partial sums meet in LDS, fixed order.
+template <int DT, int MM, int ROWS>
+__global__ __launch_bounds__(256) void gemv_fp8w_ks_k(const uint16_t* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ q,
+                                                      const float* __restrict__ sc, void* __restrict__ out, int64_t ldo,
+                                                      const uint16_t* __restrict__ resid, int64_t ldr, int N, int K, int out_f32) {
+  __shared__ float red[4][ROWS][MM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * ROWS;
+  const int nb = (K + 127) / 128;
+  const int kq = ((nb + 3) >> 2) << 7;  // elements per wave: whole 128-blocks
+  const int kb = wave * kq, ke = min(K, kb + kq);
+  float acc[ROWS][MM];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const uint8_t* qrow[ROWS];
+  const float* srow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int n = min(n0 + r, N - 1);
+    qrow[r] = q + (int64_t)n * K;
+    srow[r] = sc + (int64_t)n * nb;
+  }
+  for (int k0 = kb + lane * 16; k0 < ke; k0 += 1024) {
+    uint4 qv[ROWS];
+    float s[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      qv[r] = *(const uint4*)(qrow[r] + k0);
+      s[r] = srow[r][k0 >> 7];
+    }
+    float p[ROWS][MM];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int m = 0; m < MM; ++m) p[r][m] = 0.f;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      uint32_t w[ROWS][4];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        fp8x4_to_pk16<DT>(hlf ? qv[r].z : qv[r].x, w[r][0], w[r][1]);
+        fp8x4_to_pk16<DT>(hlf ? qv[r].w : qv[r].y, w[r][2], w[r][3]);
+      }
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const uint4 xa = *(const uint4*)(x + (int64_t)m * ldx + k0 + 8 * hlf);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          float a = p[r][m];
+          a = dot2_acc<DT>(w[r][0], xa.x, a);
+          a = dot2_acc<DT>(w[r][1], xa.y, a);
+          a = dot2_acc<DT>(w[r][2], xa.z, a);
+          a = dot2_acc<DT>(w[r][3], xa.w, a);
+          p[r][m] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int m = 0; m < MM; ++m) acc[r][m] = fmaf(s[r], p[r][m], acc[r][m]);
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const float t = wave_sum(acc[r][m]);
+      if (lane == 0) red[wave][r][m] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < ROWS * MM) {
+    const int r = threadIdx.x / MM, m = threadIdx.x % MM, n = n0 + r;
+    if (n < N) {
+      float v = (red[0][r][m] + red[1][r][m]) + (red[2][r][m] + red[3][r][m]);
+      if (resid) v += ld16<DT>(resid[(int64_t)m * ldr + n]);
+      if (out_f32) ((float*)out)[(int64_t)m * ldo + n] = v;
+      else ((uint16_t*)out)[(int64_t)m * ldo + n] = (uint16_t)st16<DT>(v);
+    }
+  }
+}
+
 // At batch 1-2 the one-wave-per-row kernel above is HBM-bound; from ~4 rows on its VALU work (rows x 8 dot2 per 16 B of weights, x 2
 // more with fp8 dequantisation) is what limits it.  Here a block owns 16 weight rows and its 8 waves split K: every lane loads 16 B of
 // one weight row STRAIGHT INTO the MFMA's B-operand registers (lane l: row l & 15, k-chunk l >> 4 - no LDS hop for the streamed
@@ -997,6 +1081,18 @@ static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float
     return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
   }
   if (M > 8) return MH_ERR_ARG;
+  if (g_gemv_ksplit && M <= 2 && !swi_ff && !norm_w && !ra.tab && N <= 8192 && K >= 2048) {  // small N, 1-2 rows: K split over the block's waves
+    const dim3 gridk((N + 1) / 2), blockk(256);
+    hipStream_t stk = as_stream(stream);
+    if (dt == MH_BF16) {
+      if (M == 1) hipLaunchKernelGGL((gemv_fp8w_ks_k<MH_BF16, 1, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+      else hipLaunchKernelGGL((gemv_fp8w_ks_k<MH_BF16, 2, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+    } else {
+      if (M == 1) hipLaunchKernelGGL((gemv_fp8w_ks_k<MH_F16, 1, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+      else hipLaunchKernelGGL((gemv_fp8w_ks_k<MH_F16, 2, 2>), gridk, blockk, 0, stk, (const uint16_t*)x, ldx, (const uint8_t*)q, scales, out, ldo, (const uint16_t*)resid, ldr, N, K, out_f32);
+    }
+    MH_LAUNCH_CHECK();
+  }
   const int rows = (swi_ff || ra.tab) ? 2 : (M < 3 ? 1 : (N >= 8192 ? 2 : 1));  // weight rows per wave (>= ~1000 blocks in flight, as in mh_gemv); SwiGLU: one gate/up pair
   const int cols = swi_ff ? rows / 2 : rows;
   const dim3 grid((N + 4 * cols - 1) / (4 * cols)), block(256);

@@ -216,12 +216,17 @@ int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, i
 int mh_quant_fp8_b128(const void* w, int64_t ldw, void* q, float* scales, int N, int K, int dt, void* stream);
 int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const float* scales, void* out, int64_t ldo, const void* resid,
                  int64_t ldr, int M, int N, int K, int dt, int out_f32, void* stream);
-/* mh_gemv / mh_gemv_fp8w take up to 16 activation rows; from 6 (16-bit weights) / 5 (fp8 weights) rows on they run as an MFMA kernel
- * (16-64 weight rows per block streamed straight into the B-operand registers, K split over 8 waves) instead of one wave per weight
- * row.  A/B switch (sets both thresholds; 17 = never): */
+/* mh_gemv / mh_gemv_fp8w take up to 16 activation rows; from 3 rows on they run as an MFMA kernel (16-64 weight rows per block
+ * streamed straight into the B-operand registers, activations straight into the A operand, K split over 8-16 waves) instead of one
+ * wave per weight row.  A/B switch (sets the threshold for both weight formats; 17 = never, <= 0 = default): */
 void mh_gemv_mfma_min_rows(int rows);
+/* Row count from which the decode projections with a paired epilogue (mh_gemv_swiglu, mh_gemv_qkv_rope, mh_gemv_fp8w_norm with ff > 0)
+ * use the MFMA form: 16-bit weights (default 6) and fp8 weights (default 4); <= 0 = default. */
+void mh_gemv_mfma_pair_min_rows(int rows16, int rows_fp8);
 /* 1-2 rows, N <= 8192 (o / down projections): 1 (default) = the four waves of a block split K (4x the waves), 0 = one wave per row pair. */
 void mh_gemv_ksplit(int on);
+/* MFMA form at N <= 8192: 1 (default) = 16 waves per block split K, 0 = 8. */
+void mh_gemv_mfma_wide(int on);
 /* Decode-step MLP gate|up projection + SwiGLU in one launch (HF LlamaMLP, modeling_llama.py:174-176, one token per sequence):
  * act[M, ff] = silu(x Wg^T) * (x Wu^T), Wgu = [Wg; Wu] [2 ff, K] row-major; gate / up are rounded to 16 bits before the
  * activation exactly as mh_gemv + mh_swiglu_fwd do (same result up to the last bit of the activation).  M <= 8. */

@@ -568,116 +568,138 @@ __global__ __launch_bounds__(256) void gemv_fp8w_ks_k(const uint16_t* __restrict
 }
 
 // At batch 1-2 the one-wave-per-row kernel above is HBM-bound; from ~4 rows on its VALU work (rows x 8 dot2 per 16 B of weights, x 2
-// more with fp8 dequantisation) is what limits it.  Here a block owns 16 weight rows and its 8 waves split K: every lane loads 16 B of
-// one weight row STRAIGHT INTO the MFMA's B-operand registers (lane l: row l & 15, k-chunk l >> 4 - no LDS hop for the streamed
-// operand), the <= 16 activation rows are the A operand from an LDS copy (row stride padded by 16 B: conflict-free fragment reads),
-// and one 16x16x32 MFMA per 1 KB of weights replaces 16 x M dot2 instructions: the kernel is HBM-bound for any M <= 16.  fp8 weights
-// (16 values per 16 B, per-128-block fp32 scales) are converted to 16-bit in registers (16 cvt per load instead of 16 x M fma) and
-// their block's partial product is scaled once per load step.  Partial tiles of the 8 waves are summed through LDS in a fixed order.
-constexpr int GM_KC = 2048;            // activation chunk in LDS: 16 rows x (2048 + 8) x 2 B = 65.8 KB
-constexpr int GM_LD = GM_KC + 8;
-// RG = 16-row groups per block (1 or 4): a block re-reads the whole activation chunk (M x K) from L2 whatever it does with it, so at
-// 16 rows per block that traffic equals the weight stream at M = 16 and the kernel is L2-bound (measured 2.9 TB/s); 64 rows per block
-// share one LDS copy and one A fragment per step between four B fragments.  Large N only: N / 64 blocks must still fill the chip.
-template <int DT, bool FP8W, int RG>
-__global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ x, int64_t ldx, const void* __restrict__ Wv, int64_t ldw,
-                                                   const float* __restrict__ wsc, void* __restrict__ out, int64_t ldo,
-                                                   const uint16_t* __restrict__ resid, int64_t ldr, int M, int N, int K, int out_f32) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];  // [16][GM_LD], then reused as float red[8][RG][64][4]
+// more with fp8 dequantisation) is what limits it.  Here a block owns 16 x RG weight rows and its NW waves split K: every lane loads
+// 16 B of one weight row STRAIGHT INTO the MFMA's B-operand registers (lane l: row l & 15, k-chunk l >> 4), and the <= 16 activation
+// rows are the A operand, ALSO loaded straight from global memory (L2-resident: M x K x 2 B): every k step is consumed by exactly one
+// wave of the block, so an LDS copy of the activations shared nothing and cost two barriers and a dependent round trip per 2 K of k
+// (the first form of this kernel: 2.5 TB/s at N = 4096).  One 16x16x32 MFMA per 1 KB of weights replaces 16 x M dot2 instructions:
+// the kernel is HBM-bound for any M <= 16.  fp8 weights (16 values per 16 B, per-128-block fp32 scales) are converted to 16-bit in
+// registers (16 cvt per load instead of 16 x M fma) and their block's partial product is scaled once per load step.  The K loop runs in
+// passes of NW waves x NS steps whose loads are all requested before the first MFMA.  Partial tiles of the NW waves are summed through
+// LDS in a fixed order.
+// RG = 16-row groups per block (1, 2 or 4): a block re-reads the whole activation matrix (M x K) from L2 whatever it does with it, so
+// at 16 rows per block that traffic equals the weight stream at M = 16 and the kernel is L2-bound (measured 2.9 TB/s); 64 rows per
+// block share one A fragment per step between four B fragments.  Large N only: N / 64 blocks must still fill the chip.
+// NW = 8, or 16 for small N (N = 4096: 256 blocks x 16 waves, i.e. twice the loads in flight at the start).
+// PAIR (RG = 2): the block's second row group is the PARTNER of the first instead of the next 16 rows, and wave 0's epilogue combines
+// them on the rounded 16-bit values, exactly as the separate launches would: 1 = SwiGLU of the gate|up projection (group 1 = up rows
+// ff + n; N = ff outputs act = silu(gate) * up), 2 = RoPE + K/V append of the q|k|v projection (group 1 = channel c + D/2 of the same
+// head; a block is 16 channels c of one head of one section; D/2 a multiple of 16).
+template <int DT, bool FP8W, int RG, int NW, int PAIR = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_k(const uint16_t* __restrict__ x, int64_t ldx, const void* __restrict__ Wv, int64_t ldw,
+                                                       const float* __restrict__ wsc, void* __restrict__ out, int64_t ldo,
+                                                       const uint16_t* __restrict__ resid, int64_t ldr, int M, int N, int K, int out_f32,
+                                                       int swi_ff, RopeAppend ra) {
+  static_assert(PAIR == 0 || RG == 2, "paired epilogues take two row groups");
+  __shared__ __attribute__((aligned(16))) float red[NW * RG * 64 * 4];
+  constexpr int KS = FP8W ? 64 : 32;                      // k per step (16 B of one weight row per lane, 4 lanes per row)
+  constexpr int NS = FP8W ? (RG == 1 ? 6 : 4) : (RG == 4 ? 4 : 8);  // steps per wave per pass (registers)
+  constexpr int KP = NW * NS * KS;                        // k per pass
+  constexpr int ES = FP8W ? 1 : 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16 * RG, j = lane & 15, kq = lane >> 4;
-  int nrow[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) nrow[g] = min(n0 + 16 * g + j, N - 1);
+  const int j = lane & 15, kq = lane >> 4;
+  int n0 = blockIdx.x * 16 * RG, goff = 16, nlim = N;  // first row, distance between the row groups, row count of W
+  if constexpr (PAIR == 1) { n0 = blockIdx.x * 16; goff = swi_ff; nlim = N + swi_ff; }
+  if constexpr (PAIR == 2) {
+    const int half = ra.D >> 1, spb = half >> 4, slot = blockIdx.x / spb;  // slot = section * H + head
+    n0 = slot * ra.D + (blockIdx.x - slot * spb) * 16;
+    goff = half;
+  }
+  const bool arow = j < M;
   f32x4_t acc[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const uint8_t* wr[RG];   // byte pointers: element size 1 (fp8) or 2
+  const float* sr[RG];
   const int nb = (K + 127) / 128;
-  for (int kc = 0; kc < K; kc += GM_KC) {
-    const int klen = min(GM_KC, K - kc);
-    if (kc) __syncthreads();
-    for (int i = tid * 8; i < 16 * klen; i += 512 * 8) {
-      const int m = i / klen, k = i - m * klen;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < M) v = *(const uint4*)(x + (int64_t)m * ldx + kc + k);
-      *(uint4*)(xs + m * GM_LD + k) = v;
-    }
-    __syncthreads();
-    if constexpr (!FP8W) {
-      // steps of 32 k, wave w takes steps w, w + 8, ...: ALL of the wave's steps of this activation chunk (8; 2 x 4 at 64 rows per block:
-      // registers) are requested before the first is consumed - with 2 K of activations per chunk a wave has only a handful of steps,
-      // and taken two at a time they were that many dependent memory round trips
-      constexpr int NS = RG == 4 ? 4 : 8;
-      const uint16_t* wr[RG];
 #pragma unroll
-      for (int g = 0; g < RG; ++g) wr[g] = (const uint16_t*)Wv + (int64_t)nrow[g] * ldw + kc + kq * 8;
-      const uint16_t* xr = xs + j * GM_LD + kq * 8;
-      for (int k0 = wave * 32; k0 < klen; k0 += 256 * NS) {
-        uint4 wv[RG][NS];
+  for (int g = 0; g < RG; ++g) {
+    const int n = PAIR == 1 ? min(n0 + j, N - 1) + g * goff : min(n0 + goff * g + j, nlim - 1);
+    acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    wr[g] = (const uint8_t*)Wv + ((int64_t)n * ldw + kq * (KS / 4)) * ES;
+    sr[g] = FP8W ? wsc + (int64_t)n * nb : nullptr;
+  }
+  const uint16_t* xr = x + (int64_t)min(j, M - 1) * ldx + kq * (KS / 4);
+  for (int kp = 0; kp < K; kp += KP) {
+    uint4 wv[RG][NS], xv[NS][FP8W ? 2 : 1];
+    float sv[FP8W ? RG : 1][FP8W ? NS : 1];
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
-#pragma unroll
-          for (int g = 0; g < RG; ++g) wv[g][u] = (k0 + u * 256 < klen) ? *(const uint4*)(wr[g] + k0 + u * 256) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-          if (k0 + u * 256 >= klen) break;
-          const uint4 xv = *(const uint4*)(xr + k0 + u * 256);
-#pragma unroll
-          for (int g = 0; g < RG; ++g) acc[g] = mfma16<DT>(xv, wv[g][u], acc[g]);
-        }
-      }
-    } else {
-      // steps of 64 k (16 fp8 per lane), wave w takes steps w, w + 8, ...: all (4) of the chunk requested at once, as above
-      constexpr int NS = 4;
-      const uint8_t* wr[RG];
-      const float* sr[RG];
+    for (int u = 0; u < NS; ++u) {
+      const int k = kp + (wave + NW * u) * KS;
+      const bool ok = k < K;
 #pragma unroll
       for (int g = 0; g < RG; ++g) {
-        wr[g] = (const uint8_t*)Wv + (int64_t)nrow[g] * ldw + kc + kq * 16;   // ldw = K bytes
-        sr[g] = wsc + (int64_t)nrow[g] * nb;
+        wv[g][u] = ok ? *(const uint4*)(wr[g] + (int64_t)k * ES) : make_uint4(0, 0, 0, 0);
+        if constexpr (FP8W) sv[g][u] = ok ? sr[g][k >> 7] : 0.f;
       }
-      const uint16_t* xr = xs + j * GM_LD + kq * 16;
-      for (int k0 = wave * 64; k0 < klen; k0 += 512 * NS) {
-        uint4 wv[RG][NS];
-        float sv[RG][NS];
+      xv[u][0] = (ok && arow) ? *(const uint4*)(xr + k) : make_uint4(0, 0, 0, 0);
+      if constexpr (FP8W) xv[u][1] = (ok && arow) ? *(const uint4*)(xr + k + 8) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
+    for (int u = 0; u < NS; ++u) {
+      if (kp + (wave + NW * u) * KS >= K) break;
+      if constexpr (!FP8W) {
 #pragma unroll
-          for (int g = 0; g < RG; ++g) {
-            const bool ok = k0 + u * 512 < klen;
-            wv[g][u] = ok ? *(const uint4*)(wr[g] + k0 + u * 512) : make_uint4(0, 0, 0, 0);
-            sv[g][u] = ok ? sr[g][(kc + k0 + u * 512) >> 7] : 0.f;
-          }
+        for (int g = 0; g < RG; ++g) acc[g] = mfma16<DT>(xv[u][0], wv[g][u], acc[g]);
+      } else {
 #pragma unroll
-        for (int u = 0; u < NS; ++u) {
-          if (k0 + u * 512 >= klen) break;
-          const uint4 x0 = *(const uint4*)(xr + k0 + u * 512), x1 = *(const uint4*)(xr + k0 + u * 512 + 8);
+        for (int g = 0; g < RG; ++g) {
+          uint4 b0, b1;  // 16 e4m3 -> 2 x 8 packed 16-bit values (exact), one convert per pair
+          fp8x4_to_pk16<DT>(wv[g][u].x, b0.x, b0.y); fp8x4_to_pk16<DT>(wv[g][u].y, b0.z, b0.w);
+          fp8x4_to_pk16<DT>(wv[g][u].z, b1.x, b1.y); fp8x4_to_pk16<DT>(wv[g][u].w, b1.z, b1.w);
+          f32x4_t part = {0.f, 0.f, 0.f, 0.f};
+          part = mfma16<DT>(xv[u][0], b0, part);
+          part = mfma16<DT>(xv[u][1], b1, part);
 #pragma unroll
-          for (int g = 0; g < RG; ++g) {
-            uint4 b0, b1;  // 16 e4m3 -> 2 x 8 packed 16-bit values (exact), one convert per pair
-            fp8x4_to_pk16<DT>(wv[g][u].x, b0.x, b0.y); fp8x4_to_pk16<DT>(wv[g][u].y, b0.z, b0.w);
-            fp8x4_to_pk16<DT>(wv[g][u].z, b1.x, b1.y); fp8x4_to_pk16<DT>(wv[g][u].w, b1.z, b1.w);
-            f32x4_t part = {0.f, 0.f, 0.f, 0.f};
-            part = mfma16<DT>(x0, b0, part);
-            part = mfma16<DT>(x1, b1, part);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][r] = fmaf(sv[g][u], part[r], acc[g][r]);
-          }
+          for (int q = 0; q < 4; ++q) acc[g][q] = fmaf(sv[g][u], part[q], acc[g][q]);
         }
       }
     }
   }
-  // D lane l reg r = D[m = 4 * (l >> 4) + r][n = l & 15]: sum the 8 waves' tiles in wave order
-  __syncthreads();
-  float* red = (float*)xs;
+  // D lane l reg r = D[m = 4 * (l >> 4) + r][n = l & 15]: sum the NW waves' tiles in wave order
 #pragma unroll
   for (int g = 0; g < RG; ++g) *(f32x4_t*)(red + ((wave * RG + g) * 64 + lane) * 4) = acc[g];
   __syncthreads();
+  if constexpr (PAIR != 0) {
+    if (wave == 0) {
+      f32x4_t s0 = *(const f32x4_t*)(red + lane * 4), s1 = *(const f32x4_t*)(red + (64 + lane) * 4);
+#pragma unroll 4
+      for (int w = 1; w < NW; ++w) {
+        const f32x4_t t0 = *(const f32x4_t*)(red + ((w * 2) * 64 + lane) * 4), t1 = *(const f32x4_t*)(red + ((w * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] += t0[r]; s1[r] += t1[r]; }
+      }
+      uint16_t* o16 = (uint16_t*)out;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * kq + r;
+        if (m >= M) continue;
+        float lo = ld16<DT>((uint16_t)st16<DT>(s0[r])), hi = ld16<DT>((uint16_t)st16<DT>(s1[r]));  // the projection as it would be stored
+        if constexpr (PAIR == 1) {
+          if (n0 + j < N) o16[(int64_t)m * ldo + n0 + j] = (uint16_t)st16<DT>(swiglu_fwd1(lo, hi));
+        } else {
+          const int half = ra.D >> 1, slot = n0 / ra.D, sec = slot / ra.H, c = n0 - slot * ra.D + j, p = ra.pos[m];
+          const int64_t HD = (int64_t)ra.H * ra.D, col = (int64_t)(slot - sec * ra.H) * ra.D + c;
+          if (sec < 2) {
+            const float2 cs = ra.tab[(int64_t)p * half + c];
+            rope_rot(lo, hi, cs.x, cs.y, lo, hi);
+          }
+          const uint16_t l16 = (uint16_t)st16<DT>(lo), h16 = (uint16_t)st16<DT>(hi);
+          o16[(int64_t)m * ldo + sec * HD + col] = l16;
+          o16[(int64_t)m * ldo + sec * HD + col + half] = h16;
+          if (sec > 0) {
+            uint16_t* dst = (sec == 1 ? ra.kc : ra.vc) + ((int64_t)m * ra.Smax + p) * HD + col;
+            dst[0] = l16;
+            dst[half] = h16;
+          }
+        }
+      }
+    }
+    return;
+  }
   if (wave < RG) {
     const int g = wave;
     f32x4_t s4 = *(const f32x4_t*)(red + (g * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < 8; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const f32x4_t t = *(const f32x4_t*)(red + ((w * RG + g) * 64 + lane) * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s4[r] += t[r];
@@ -697,28 +719,26 @@ __global__ __launch_bounds__(512) void gemv_mfma_k(const uint16_t* __restrict__ 
   }
 }
 
+static int g_gemv_mfma_nw16 = 1;  // 16 waves per block at small N (A-B switch: mh_gemv_mfma_wide)
+extern "C" void mh_gemv_mfma_wide(int on) { g_gemv_mfma_nw16 = on ? 1 : 0; }
+
 template <int DT, bool FP8W>
 static int launch_gemv_mfma(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* wsc, void* out, int64_t ldo, const void* resid,
-                            int64_t ldr, int M, int N, int K, int out_f32, hipStream_t st) {
-  constexpr int lds = 16 * GM_LD * 2;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void*)gemv_mfma_k<DT, FP8W, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
+                            int64_t ldr, int M, int N, int K, int out_f32, int swi_ff, const RopeAppend& ra, hipStream_t st) {
+  // rows per block: as many as still give ~1.5+ blocks per CU: measured, 64-row blocks win at N = 32 064 (501 blocks) and lose at
+  // N = 22 016 (344 blocks: an uneven second block per CU)
+#define MH_GM(RG_, NW_, PAIR_, BLOCKS_)                                                                                                \
+  hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, RG_, NW_, PAIR_>), dim3(BLOCKS_), dim3(64 * NW_), 0, st, (const uint16_t*)x, ldx, W, ldw, wsc, \
+                     out, ldo, (const uint16_t*)resid, ldr, M, N, K, out_f32, swi_ff, ra)
+  if (swi_ff) MH_GM(2, 8, 1, (N + 15) / 16);           // N = ff outputs
+  else if (ra.tab) {                                   // N = 3 H D rows, 16 rotary pairs per block (N = 12 288: 384 blocks)
+    if (g_gemv_mfma_nw16) MH_GM(2, 16, 2, N / 32); else MH_GM(2, 8, 2, N / 32);
   }
-  // rows per block: as many as still give ~1.5+ blocks per CU (two 66 KB blocks fit a CU): measured, 64-row blocks win at N = 32 064
-  // (501 blocks) and lose at N = 22 016 (344 blocks: an uneven second block per CU)
-  if (N >= 30000)
-    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 4>), dim3((N + 63) / 64), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
-                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
-  else if (N >= 12000)
-    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 2>), dim3((N + 31) / 32), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
-                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
-  else
-    hipLaunchKernelGGL((gemv_mfma_k<DT, FP8W, 1>), dim3((N + 15) / 16), dim3(512), lds, st, (const uint16_t*)x, ldx, W, ldw, wsc, out, ldo,
-                       (const uint16_t*)resid, ldr, M, N, K, out_f32);
+  else if (N >= 30000) MH_GM(4, 8, 0, (N + 63) / 64);
+  else if (N >= 12000) MH_GM(2, 8, 0, (N + 31) / 32);
+  else if (N <= 8192 && g_gemv_mfma_nw16) MH_GM(1, 16, 0, (N + 15) / 16);
+  else MH_GM(1, 8, 0, (N + 15) / 16);
+#undef MH_GM
   MH_LAUNCH_CHECK();
 }
 
@@ -903,14 +923,21 @@ __global__ __launch_bounds__(D) void attn_decode_combine_k(const float* __restri
 
 }  // namespace
 
-// activation-row count from which the MFMA form is used (measured crossovers, profiles/r02_gemv_ab.txt: 16-bit weights ~6 rows, fp8
-// weights ~5: below that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
-static int g_gemv_mfma_min_rows = 6, g_gemv_mfma_min_rows_fp8 = 5;
+// activation-row count from which the MFMA form is used (measured, profiles/r02_gemv_ab.txt: 3 rows for both weight formats - below
+// that the one-wave-per-row kernels stream faster); mh_gemv_mfma_min_rows(r) overrides both (A/B switch; 17 = never)
+static int g_gemv_mfma_min_rows = 3, g_gemv_mfma_min_rows_fp8 = 3;
+// the forms with a paired epilogue (SwiGLU, RoPE + append) compete with one-wave-per-row-pair kernels that already fuse the same work
+// and stream at 4.3-4.5 TB/s up to ~5 rows: measured crossover 6 rows with 16-bit weights, 4 with fp8 (mh_gemv_mfma_pair_min_rows)
+static int g_gemv_mfma_pair_min = 6, g_gemv_mfma_pair_min_fp8 = 4;
 static int g_gemv_ksplit = 1;  // 1-2 rows, N <= 8192: K split over the four waves of a block (A-B switch: mh_gemv_ksplit)
 extern "C" void mh_gemv_ksplit(int on) { g_gemv_ksplit = on ? 1 : 0; }
 extern "C" void mh_gemv_mfma_min_rows(int rows) {
-  if (rows <= 0) { g_gemv_mfma_min_rows = 6; g_gemv_mfma_min_rows_fp8 = 5; }  // restore the defaults
-  else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = rows;
+  if (rows <= 0) { g_gemv_mfma_min_rows = 3; g_gemv_mfma_min_rows_fp8 = 3; g_gemv_mfma_pair_min = 6; g_gemv_mfma_pair_min_fp8 = 4; }  // the defaults
+  else g_gemv_mfma_min_rows = g_gemv_mfma_min_rows_fp8 = g_gemv_mfma_pair_min = g_gemv_mfma_pair_min_fp8 = rows;
+}
+extern "C" void mh_gemv_mfma_pair_min_rows(int rows16, int rows_fp8) {
+  g_gemv_mfma_pair_min = rows16 > 0 ? rows16 : 6;
+  g_gemv_mfma_pair_min_fp8 = rows_fp8 > 0 ? rows_fp8 : 4;
 }
 
 static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t ldo, const void* resid,
@@ -920,10 +947,13 @@ static int gemv_impl(const void* x, int64_t ldx, const void* W, int64_t ldw, voi
   if (!aligned16(x) || !aligned16(W)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   if (norm_w && (M > 8 || K > 8192 || !aligned16(norm_w))) return MH_ERR_ARG;  // fused RMSNorm: row-per-wave form, whole row in LDS
-  if (ra.tab && (M > 8 || swi_ff || (N & 1))) return MH_ERR_ARG;
-  if (!swi_ff && !norm_w && !ra.tab && M >= g_gemv_mfma_min_rows && (K % 32) == 0) {  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound
-    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
-    return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+  if (ra.tab && (swi_ff || (N & 1))) return MH_ERR_ARG;
+  if ((swi_ff || ra.tab) && (resid || out_f32)) return MH_ERR_ARG;
+  // 3+ rows: the MFMA form (above) is HBM-bound where this one turns VALU-bound (the rotary-pair form needs D/2 to be whole 16-row groups)
+  if (!norm_w && M >= ((swi_ff || ra.tab) ? g_gemv_mfma_pair_min : g_gemv_mfma_min_rows) && (K % 32) == 0 &&
+      (!ra.tab || ((ra.D >> 1) % 16 == 0 && N == 3 * ra.H * ra.D))) {
+    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, swi_ff, ra, as_stream(stream));
+    return launch_gemv_mfma<MH_F16, false>(x, ldx, W, ldw, nullptr, out, ldo, resid, ldr, M, N, K, out_f32, swi_ff, ra, as_stream(stream));
   }
   if (M > 8) return MH_ERR_ARG;
   // weight rows per wave: as many as keep >= ~1000 blocks in flight (N = 4096 with 4 rows per wave is 256 blocks = one per
@@ -986,10 +1016,10 @@ extern "C" int mh_gemv(const void* x, int64_t ldx, const void* W, int64_t ldw, v
   return gemv_impl(x, ldx, W, ldw, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, RopeAppend{}, stream);
 }
 // act[M, ff] = silu(x Wg^T) * (x Wu^T) with Wgu = [Wg; Wu] [2 ff, K] (HF LlamaMLP gate / up of the decode step): one launch, the
-// gate|up projection never reaches memory (gate / up are rounded to 16 bits before the activation, as the two launches do).  M <= 8 rows.
+// gate|up projection never reaches memory (gate / up are rounded to 16 bits before the activation, as the two launches do).  M <= 16 rows (MFMA form from 3 rows on).
 extern "C" int mh_gemv_swiglu(const void* x, int64_t ldx, const void* Wgu, int64_t ldw, void* act, int64_t ldo, int M, int ff, int K, int dt,
                               void* stream) {
-  if (ff <= 0 || M > 8) return MH_ERR_ARG;
+  if (ff <= 0) return MH_ERR_ARG;
   return gemv_impl(x, ldx, Wgu, ldw, act, ldo, nullptr, 0, M, ff, K, dt, 0, ff, nullptr, 0.f, RopeAppend{}, stream);
 }
 // The same two projections with the RMSNorm that precedes them (HF LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm ->
@@ -1074,13 +1104,15 @@ static int gemv_fp8w_impl(const void* x, int64_t ldx, const void* q, const float
   if (!x || !q || !scales || !out || M <= 0 || M > 16 || N <= 0 || K <= 0 || (K & 15) || (ldx & 7)) return MH_ERR_ARG;
   if (!aligned16(x) || !aligned16(q)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
-  if ((norm_w || swi_ff || ra.tab) && (M > 8 || K > 8192 || (norm_w && !aligned16(norm_w)))) return MH_ERR_ARG;
+  if (norm_w && (M > 8 || K > 8192 || !aligned16(norm_w))) return MH_ERR_ARG;
   if (ra.tab && (swi_ff || (N & 1))) return MH_ERR_ARG;
-  if (!norm_w && !swi_ff && !ra.tab && M >= g_gemv_mfma_min_rows_fp8 && (K % 64) == 0) {
-    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
-    return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, as_stream(stream));
+  if ((swi_ff || ra.tab) && (resid || out_f32)) return MH_ERR_ARG;
+  if (!norm_w && M >= ((swi_ff || ra.tab) ? g_gemv_mfma_pair_min_fp8 : g_gemv_mfma_min_rows_fp8) && (K % 64) == 0 &&
+      (!ra.tab || ((ra.D >> 1) % 16 == 0 && N == 3 * ra.H * ra.D))) {
+    if (dt == MH_BF16) return launch_gemv_mfma<MH_BF16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, swi_ff, ra, as_stream(stream));
+    return launch_gemv_mfma<MH_F16, true>(x, ldx, q, K, scales, out, ldo, resid, ldr, M, N, K, out_f32, swi_ff, ra, as_stream(stream));
   }
-  if (M > 8) return MH_ERR_ARG;
+  if (M > 8 || ((swi_ff || ra.tab) && K > 8192)) return MH_ERR_ARG;
   if (g_gemv_ksplit && M <= 2 && !swi_ff && !norm_w && !ra.tab && N <= 8192 && K >= 2048) {  // small N, 1-2 rows: K split over the block's waves
     const dim3 gridk((N + 1) / 2), blockk(256);
     hipStream_t stk = as_stream(stream);
@@ -1141,10 +1173,10 @@ extern "C" int mh_gemv_fp8w(const void* x, int64_t ldx, const void* q, const flo
   return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, resid, ldr, M, N, K, dt, out_f32, 0, nullptr, 0.f, RopeAppend{}, stream);
 }
 // mh_gemv_norm with fp8 (e4m3, per-128-block scales) weights: out = rmsnorm(x; norm_w, eps) W^T (norm_w may be NULL: no norm), ff > 0: SwiGLU of the
-// gate|up rows.  M <= 8, K <= 8192.
+// gate|up rows.  With norm_w: M <= 8, K <= 8192; without: M <= 16.
 extern "C" int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps, const void* q, const float* scales, void* out,
                                  int64_t ldo, int M, int N, int K, int ff, int dt, void* stream) {
-  if (M > 8 || ff < 0) return MH_ERR_ARG;
+  if (ff < 0) return MH_ERR_ARG;
   return gemv_fp8w_impl(x, ldx, q, scales, out, ldo, nullptr, 0, M, ff > 0 ? ff : N, K, dt, 0, ff, norm_w, eps, RopeAppend{}, stream);
 }
 
@@ -1154,7 +1186,7 @@ extern "C" int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w,
 extern "C" int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, const void* q8,
                                 const float* scales, void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos,
                                 void* kcache, void* vcache, int H, int D, int Smax, void* stream) {
-  if (!cos_sin || !pos || !kcache || !vcache || H <= 0 || D <= 0 || (D & 1) || Smax <= 0 || M > 8 || (!W && !(q8 && scales))) return MH_ERR_ARG;
+  if (!cos_sin || !pos || !kcache || !vcache || H <= 0 || D <= 0 || (D & 1) || Smax <= 0 || (!W && !(q8 && scales))) return MH_ERR_ARG;
   RopeAppend ra;
   ra.tab = (const float2*)cos_sin; ra.pos = pos; ra.kc = (uint16_t*)kcache; ra.vc = (uint16_t*)vcache; ra.H = H; ra.D = D; ra.Smax = Smax;
   const int N = 3 * H * D;

@@ -67,15 +67,23 @@ template <int DT> __device__ __forceinline__ uint4 pack8(const float* f) {
 
 // rotate-half RoPE of one (x[i], x[i + D/2]) pair; ONE definition with explicit fmas so that the stand-alone kernel, the
 // decode kernel and the GEMM-epilogue form round identically (inverse: pass -sin)
+// The fp32 results pass through an empty asm: without it hipcc may merge the fma with the caller's 16-bit store conversion into ONE
+// v_fma_mix*_f16 (a single rounding from the exact value) in some callers and not in others, and the kernels then disagree wherever
+// the fp32 result is a 16-bit tie (found by tests/test_ops_gpu.py: fused q|k|v epilogue vs mh_decode_rope_append).
+__device__ __forceinline__ float fp32_value(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
 __device__ __forceinline__ void rope_rot(float a, float b, float c, float s, float& lo, float& hi) {
-  lo = fmaf(a, c, -(b * s));
-  hi = fmaf(b, c, a * s);
+  const float l = fmaf(a, c, -(b * s)), h = fmaf(b, c, a * s);
+  lo = fp32_value(l);
+  hi = fp32_value(h);
 }
 
 // SwiGLU element maths, ONE definition (explicit fma) shared by the stand-alone kernels and the GEMM-epilogue forms so that
 // both round identically: act = silu(g) * u;  d_up = d * g * sig(g);  d_gate = d * u * sig(g) * (1 + g * (1 - sig(g)))
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float swiglu_fwd1(float g, float u) { return g * sigmoidf_(g) * u; }
+__device__ __forceinline__ float swiglu_fwd1(float g, float u) { return fp32_value(g * sigmoidf_(g) * u); }
 __device__ __forceinline__ void swiglu_bwd1(float g, float u, float d, float& dg, float& du) {
   const float s = sigmoidf_(g);
   du = d * g * s;

@@ -149,7 +149,7 @@ def gemv_swiglu(x, wgu, out=None):
     M, K = x.shape
     ff = wgu.shape[0] // 2
     assert wgu.shape[1] == K and x.dtype == wgu.dtype
-    if M > 8:
+    if not _gemv_fused_rows_ok(M, K):
         return swiglu_fwd(gemv(x, wgu), out=out)
     out = torch.empty(M, ff, dtype=x.dtype, device=x.device) if out is None else out
     L.check(L.lib().mh_gemv_swiglu(p(x), i64(_rowmajor(x)), p(wgu), i64(_rowmajor(wgu)), p(out), i64(_rowmajor(out)), i32(M), i32(ff), i32(K),
@@ -167,7 +167,7 @@ def gemv_norm(x, norm_w, eps, w, swiglu=False, out=None):
     M, K = x.shape
     if M > FUSED_NORM_MAX_ROWS or K > 8192:
         h = rmsnorm_fwd(x, norm_w, eps)
-        return gemv_swiglu(h, w, out=out) if swiglu else gemv(h, w, out=out)  # (gemv_swiglu: fused up to 8 rows)
+        return gemv_swiglu(h, w, out=out) if swiglu else gemv(h, w, out=out)  # (gemv_swiglu: fused up to 16 rows)
     N = w.shape[0]
     ff = N // 2 if swiglu else 0
     assert w.shape[1] == K and x.dtype == w.dtype == norm_w.dtype and x.is_contiguous()
@@ -206,12 +206,12 @@ def gemv_fp8w(x, qw, out=None, resid=None, out_f32=False, n=None):
 
 def gemv_fp8w_norm(x, norm_w, eps, qw, swiglu=False, out=None):
     """gemv_norm with fp8 weights (qw = (q, scales) from quant_fp8_b128).  1-2 rows: norm, projection (and SwiGLU) in one launch;
-    3-8 rows: separate norm, SwiGLU still fused; more rows: separate launches."""
+    3-16 rows: separate norm, SwiGLU still fused; more rows: separate launches."""
     q, sc = qw
     M, K = x.shape
     N = q.shape[0]
     ff = N // 2 if swiglu else 0
-    if M > 8 or K > 8192:
+    if not _gemv_fused_rows_ok(M, K) or K > 8192:
         y = gemv_fp8w(rmsnorm_fwd(x, norm_w, eps), qw)
         return swiglu_fwd(y, out=out) if swiglu else y
     fuse_norm = M <= FUSED_NORM_MAX_ROWS
@@ -228,10 +228,10 @@ def gemv_fp8w_norm(x, norm_w, eps, qw, swiglu=False, out=None):
 
 def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D):
     """Decode-step q|k|v: (input_layernorm +) projection + RoPE at pos + K/V append in one launch; w = 16-bit weight [3HD, K] or the
-    (q, scales) pair of quant_fp8_b128.  Returns qkv [M, 3HD] (q, k rotated).  More than 8 rows: the separate launches."""
+    (q, scales) pair of quant_fp8_b128.  Returns qkv [M, 3HD] (q, k rotated).  More than 16 rows: the separate launches."""
     M, K = x.shape
     fp8 = isinstance(w, (tuple, list))
-    if M > 8 or K > 8192:
+    if not _gemv_fused_rows_ok(M, K) or K > 8192 or (M > 8 and (D // 2) % 16):
         h = rmsnorm_fwd(x, norm_w, eps)
         qkv = gemv_fp8w(h, w) if fp8 else gemv(h, w)
         decode_rope_append(qkv, table, pos, kcache, vcache, H, D)
@@ -887,14 +887,34 @@ def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
 
 
+_gemv_mfma_min = 3
+
+
 def gemv_mfma_min_rows(rows: int):
-    """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (<= 0 restores the measured defaults; 17 = never)."""
+    """A/B switch: row count from which gemv / gemv_fp8w use the MFMA kernel (<= 0 restores the measured default, 3; 17 = never)."""
+    global _gemv_mfma_min
+    _gemv_mfma_min = rows if rows > 0 else 3
     L.lib().mh_gemv_mfma_min_rows(i32(rows))
+
+
+def gemv_mfma_pair_min_rows(rows16: int, rows_fp8: int):
+    """A/B switch: row counts from which the SwiGLU / RoPE-append projections use the MFMA form (<= 0: defaults 6 / 4)."""
+    L.lib().mh_gemv_mfma_pair_min_rows(i32(rows16), i32(rows_fp8))
+
+
+def _gemv_fused_rows_ok(M, K):
+    """Rows the fused decode projections (SwiGLU / RoPE epilogues) take in one launch: 8 as one wave per row pair, 16 in the MFMA form."""
+    return M <= 8 or (M <= 16 and M >= _gemv_mfma_min and K % 64 == 0)
 
 
 def gemv_ksplit(on: bool):
     """A/B switch: K split over a block's waves in the 1-2 row GEMV at N <= 8192 (default on)."""
     L.lib().mh_gemv_ksplit(i32(1 if on else 0))
+
+
+def gemv_mfma_wide(on: bool):
+    """A/B switch: 16 instead of 8 waves per block in the MFMA GEMV at N <= 8192 (default on)."""
+    L.lib().mh_gemv_mfma_wide(i32(1 if on else 0))
 
 
 def gemm_raster_group(gm: int):

@@ -497,14 +497,15 @@ def test_gemv_swiglu_fused(ops, dtype, M, ff, K):
     """Decode-step gate|up projection + SwiGLU in one launch = the two launches (gate / up rounded to 16 bits before the activation;
     the activation itself may round differently in the last bit), and HF LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) in fp32."""
     x, wgu = rnd(M, K, dtype=dtype), rnd(2 * ff, K, dtype=dtype, seed=1, scale=0.1)
-    one = ops.gemv_swiglu(x, wgu)
-    if M <= 8:
-        try:
-            ops.gemv_mfma_min_rows(17)  # the reference pair on the same (row-per-wave) GEMV form
+    try:
+        if M <= 8:
+            ops.gemv_mfma_min_rows(17)  # both sides on the row-per-wave GEMV form (the MFMA form: test_gemv_swiglu_fused_mfma_form)
+        one = ops.gemv_swiglu(x, wgu)
+        if M <= 8:
             two = ops.swiglu_fwd(ops.gemv(x, wgu))
-        finally:
-            ops.gemv_mfma_min_rows(0)
-        assert float((one != two).float().mean()) < 1e-3 and relerr(one, two) < EPS16[dtype]
+            assert float((one != two).float().mean()) < 1e-3 and relerr(one, two) < EPS16[dtype]
+    finally:
+        ops.gemv_mfma_min_rows(0)
     gu = (x.float() @ wgu.float().t()).to(dtype).float()  # the projection as the reference stores it
     ref = torch.nn.functional.silu(gu[:, :ff]) * gu[:, ff:]
     assert relerr(one, ref) < 4 * EPS16[dtype]
@@ -584,6 +585,68 @@ def test_qkv_projection_with_fused_norm_rope_append(ops, dtype, fp8, B, H, D, K,
     finally:
         ops.gemv_mfma_min_rows(0)
         ops.FUSED_NORM_MAX_ROWS = keep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,ff,K", [(3, 11008, 4096), (4, 136, 256), (8, 1000, 4096), (11, 11008, 4096), (16, 520, 1024)])
+def test_gemv_swiglu_fused_mfma_form(ops, dtype, fp8, M, ff, K):
+    """3-16 rows: the gate|up projection runs as the MFMA GEMV whose blocks own 16 gate rows AND their up rows and apply SwiGLU in the
+    epilogue = MFMA GEMV (8-wave form: same summation order) + swiglu_fwd up to the activation's last bit."""
+    x, wgu = rnd(M, K, dtype=dtype), rnd(2 * ff, K, dtype=dtype, seed=1, scale=0.1)
+    qw = ops.quant_fp8_b128(wgu) if fp8 else None
+    try:
+        ops.gemv_mfma_pair_min_rows(3, 3)  # (defaults 6 / 4: below that the one-wave-per-row-pair form is used)
+        one = ops.gemv_fp8w_norm(x, rnd(K, dtype=dtype, seed=3), 1e-6, qw, swiglu=True) if fp8 else ops.gemv_swiglu(x, wgu)
+        ops.gemv_mfma_wide(False)
+        if fp8:
+            two = ops.swiglu_fwd(ops.gemv_fp8w(ops.rmsnorm_fwd(x, rnd(K, dtype=dtype, seed=3), 1e-6), qw))
+        else:
+            two = ops.swiglu_fwd(ops.gemv(x, wgu))
+    finally:
+        ops.gemv_mfma_wide(True)
+        ops.gemv_mfma_pair_min_rows(0, 0)
+    assert one.shape == (M, ff)
+    assert int((one != two).sum()) <= max(2, one.numel() // 1000) and relerr(one, two) < EPS16[dtype]  # (last bit of the activation)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,H,D,K,Smax,pos", [(3, 32, 128, 4096, 64, [17, 0, 63]), (5, 2, 64, 256, 16, [3, 0, 15, 7, 7]),
+                                              (8, 4, 128, 1024, 24, list(range(8))), (16, 2, 128, 512, 20, list(range(16)))])
+def test_qkv_projection_rope_append_mfma_form(ops, dtype, fp8, B, H, D, K, Smax, pos):
+    """3-16 rows: q|k|v projection + RoPE + K/V append as the MFMA GEMV whose blocks own 16 channels c of a head and their partners
+    c + D/2 = rmsnorm + MFMA GEMV (8-wave form) + decode_rope_append, bit for bit (qkv buffer and cache)."""
+    d = H * D
+    x, g, w = rnd(B, K, dtype=dtype), rnd(K, dtype=dtype, seed=3), rnd(3 * d, K, dtype=dtype, seed=1, scale=0.1)
+    wq = ops.quant_fp8_b128(w) if fp8 else w
+    tab = ops.rope_table(Smax, D, 10000.0, dev())
+    p32 = torch.tensor(pos, dtype=torch.int32, device=dev())
+    kc0, vc0 = rnd(B, Smax, d, dtype=dtype, seed=5), rnd(B, Smax, d, dtype=dtype, seed=6)
+    h = ops.rmsnorm_fwd(x, g, 1e-6)
+    try:
+        ops.gemv_mfma_wide(False)
+        ref = ops.gemv_fp8w(h, wq) if fp8 else ops.gemv(h, w)
+    finally:
+        ops.gemv_mfma_wide(True)
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    ops.decode_rope_append(ref, tab, p32, kc1, vc1, H, D)
+    kc2, vc2, kc3, vc3 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+    try:
+        ops.gemv_mfma_pair_min_rows(3, 3)  # (defaults 6 / 4: below that the one-wave-per-row-pair form is used)
+        ops.gemv_mfma_wide(False)
+        got = ops.gemv_qkv_rope(x, g, 1e-6, wq, tab, p32, kc2, vc2, H, D)
+        ops.gemv_mfma_wide(True)
+        # the default form splits K over 16 waves (another summation order): the same values within 16-bit rounding
+        got16 = ops.gemv_qkv_rope(x, g, 1e-6, wq, tab, p32, kc3, vc3, H, D)
+    finally:
+        ops.gemv_mfma_wide(True)
+        ops.gemv_mfma_pair_min_rows(0, 0)
+    assert torch.equal(got, ref) and torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    assert relerr(got16, ref) < EPS16[dtype] and relerr(kc3, kc1) < EPS16[dtype] and relerr(vc3, vc1) < EPS16[dtype]
+    untouched = torch.ones(B, Smax, dtype=torch.bool, device=dev())
+    untouched[torch.arange(B, device=dev()), p32.long()] = False
+    assert torch.equal(kc3[untouched], kc0[untouched]) and torch.equal(vc3[untouched], vc0[untouched])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -10,6 +10,10 @@ from merlin_amd import synth
 from merlin_amd import ops as _O
 if os.environ.get("MH_GEMV_MFMA_MIN"):  # A/B: 17 = never use the MFMA GEMV
     _O.gemv_mfma_min_rows(int(os.environ["MH_GEMV_MFMA_MIN"]))
+if os.environ.get("MH_GEMV_PAIR_MIN"):  # A/B: "rows16,rows_fp8" from which the SwiGLU / RoPE projections use the MFMA form
+    _O.gemv_mfma_pair_min_rows(*[int(a) for a in os.environ["MH_GEMV_PAIR_MIN"].split(",")])
+if os.environ.get("MH_GEMV_MFMA_WIDE"):  # A/B: 0 = 8 waves per block in the small-N MFMA GEMV
+    _O.gemv_mfma_wide(os.environ["MH_GEMV_MFMA_WIDE"] != "0")
 if os.environ.get("MH_GEMV_KSPLIT"):  # A/B: 0 = one wave per row pair in the small-N GEMV
     _O.gemv_ksplit(os.environ["MH_GEMV_KSPLIT"] != "0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -5,6 +5,9 @@ import torch
 from merlin_amd import ops as O
 
 dev = torch.device("cuda:0")
+if os.environ.get("MH_GEMV_MFMA_WIDE"):  # A/B: 0 = 8 waves per block in the small-N MFMA form
+    O.gemv_mfma_wide(os.environ["MH_GEMV_MFMA_WIDE"] != "0")
+MS = tuple(int(a) for a in sys.argv[1:]) or (1, 2, 4, 8, 16)
 
 
 def timeit(fn, iters=20, warm=5):
@@ -26,7 +29,7 @@ for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32064
     # rotate over several weight copies so the 256 MB Infinity Cache does not serve the stream
     ws = [w.clone() for _ in range(max(1, int(600e6 // (N * K * 2))))]
     q8s = [(q8[0].clone(), q8[1].clone()) for _ in range(max(1, int(600e6 // (N * K))))]
-    for M in (1, 2, 4, 8, 16):
+    for M in MS:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         row = f"N={N:5d} K={K:5d} M={M:2d}:"
         for mode, mn in (("row-wave", 17), ("mfma", 3)):

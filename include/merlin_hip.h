@@ -203,6 +203,8 @@ int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
 int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                  const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
                  void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt, void* stream);
+/* dK and dV from one kernel (scores and dP computed once per tile; default) or from two (0): A/B switch. */
+void mh_attn_bwd_fused_kv(int on);
 /* ---- KV-cache decode (S_q = 1): generate() behind llama_mmgpt.py:114-134 / eval_mmvet.py:101-120 ------------------
  * HF LlamaAttention with past_key_values (modeling_llama.py:243-281): q,k of the new token rotated at its own
  * position, k,v appended to the cache, softmax(q K^T / sqrt(D)) V over keys [0, len).  All HBM-bound kernels. */

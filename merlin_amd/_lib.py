@@ -46,6 +46,8 @@ def lib() -> C.CDLL:
             _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
         if os.environ.get("MH_GEMM_PERSISTENT") == "0":  # A/B switches for benchmarks
             _lib.mh_gemm_persistent(C.c_int(0))
+        if os.environ.get("MH_ATTN_BWD_FUSED_KV") == "0":
+            _lib.mh_attn_bwd_fused_kv(C.c_int(0))
         if os.environ.get("MH_GEMM_GM"):
             _lib.mh_gemm_raster_group(C.c_int(int(os.environ["MH_GEMM_GM"])))
     return _lib

@@ -106,6 +106,72 @@ __device__ __forceinline__ void stream_tr_frags(const unsigned* addr, F&& consum
   });
 }
 
+// MFMA whose accumulator is pinned in AccVGPRs (inline asm): for accumulators nothing but MFMAs touches until the epilogue.  The
+// fused dK + dV kernel needs ~400 registers; left to itself hipcc keeps the score / dP accumulators in AccVGPRs instead and moves
+// every element in and out around the softmax arithmetic (128 of the 330 VALU instructions of a tile).
+template <int DT>
+__device__ __forceinline__ void mfma32a(f32x16_t& acc, const u32x4_t& x, const u32x4_t& y) {
+  if constexpr (DT == MH_BF16)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+}
+// MFMA with the accumulator in VGPRs and the B operand in AccVGPRs (the wave's resident K / V fragments).  hipcc cannot see that
+// these asm statements are MFMAs, so the wait states it would insert are written out: mfma_settle() between the last MFMA of a chain
+// and the first VALU read of its accumulator (19 wait states cover the longest XDL write -> VALU read rule), mfma_ready() between
+// the VALU / LDS writes that initialise an accumulator and the first MFMA that reads it (2).
+template <int DT>
+__device__ __forceinline__ void mfma32va(f32x16_t& acc, const u32x4_t& x, const u32x4_t& y) {
+  if constexpr (DT == MH_BF16)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "a"(y));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "a"(y));
+}
+__device__ __forceinline__ void mfma_settle(f32x16_t& a, f32x16_t& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mfma_ready(f32x16_t& a, f32x16_t& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mfma_settle_acc(f32x16_t& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a)); }
+// 16 bytes from global memory straight into AccVGPRs (waited for by the caller's s_waitcnt vmcnt)
+template <int OFF>
+__device__ __forceinline__ void gload128_acc(u32x4_t& d, const void* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(d) : "v"(ptr), "n"(OFF) : "memory");
+}
+
+// Two row-fragment streams interleaved (fragment n: tile at +OFF0 for even n, +OFF1 for odd n, k-step n / 2): two independent MFMA
+// chains alternate, so neither waits for its own previous accumulate.  consume(n, frag) may also carry a slice of VALU work.
+template <int OFF0, int OFF1, int KS, typename F>
+__device__ __forceinline__ void stream_row_frags2(const unsigned* addr, F&& consume) {
+  constexpr int NF = 2 * KS, W = 8;
+  u32x4_t w[W];
+  static_for<W>([&](auto I) { constexpr int n = decltype(I)::value; lds_read128<(n % 2) ? OFF1 : OFF0>(w[n], addr[n / 2]); });
+  static_for<NF>([&](auto I) {
+    constexpr int n = decltype(I)::value;
+    constexpr int left = NF - 1 - n;
+    lgkm_wait<(left < W - 1 ? left : W - 1)>();
+    consume(I, w[n % W]);
+    if constexpr (n + W < NF) lds_read128<((n + W) % 2) ? OFF1 : OFF0>(w[n % W], addr[(n + W) / 2]);
+  });
+}
+// The same for transposed fragments: stream element g = (tile g % 2, fragment g / 2), fragment f = (d-block f / 2, k-step f % 2).
+template <int RB, int R0, int OFF0, int OFF1, int NFH, typename F>
+__device__ __forceinline__ void stream_tr_frags2(const unsigned* addr, F&& consume) {
+  constexpr int NF = 2 * NFH, W = 4;
+  u32x2_t w[2 * W];
+  auto issue = [&](auto G, auto SLOT) {
+    constexpr int g = decltype(G)::value, sl = decltype(SLOT)::value, f = g / 2, off = (g % 2) ? OFF1 : OFF0;
+    lds_read64_tr<(R0 + (f % 2) * 16) * RB + off>(w[2 * sl], addr[2 * (f / 2)]);
+    lds_read64_tr<(R0 + (f % 2) * 16 + 8) * RB + off>(w[2 * sl + 1], addr[2 * (f / 2) + 1]);
+  };
+  static_for<W>([&](auto I) { issue(I, I); });
+  static_for<NF>([&](auto I) {
+    constexpr int g = decltype(I)::value;
+    constexpr int left = NF - 1 - g;
+    lgkm_wait<2 * (left < W - 1 ? left : W - 1)>();
+    const u32x4_t fr = u32x4_t{w[2 * (g % W)][0], w[2 * (g % W)][1], w[2 * (g % W) + 1][0], w[2 * (g % W) + 1][1]};
+    consume(I, fr);
+    if constexpr (g + W < NF) issue(std::integral_constant<int, g + W>{}, std::integral_constant<int, g % W>{});
+  });
+}
+
 // Inverse RoPE of one gradient row held in the epilogue layout (lane: channels 32*i + 8*g + 4*hi + e of its row): the
 // partner of channel d < D/2 is d + D/2 = accumulator block i + DBLK/2 of the SAME lane, so the rotation is in registers.
 // tab points at the (cos, sin) row of this lane's sequence position.  Gradient of y = rope(x): x_bar = rope^T(y_bar) =
@@ -272,9 +338,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
 // dV (MODE 1) / dK (MODE 2)
 // ------------------------------------------------------------------------------------------------------------
 template <int DT, int D, bool CAUSAL, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
+__global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DO_DK = (MODE == 2);
+  // MODE 1: dV, 2: dK (two waves per SIMD each), 3: both from ONE score / dP computation per tile (one wave per SIMD: the two
+  // accumulator sets, K and V fragments are ~200 registers before anything else)
+  constexpr bool DO_DK = (MODE & 2) != 0, DO_DV = (MODE & 1) != 0;
+  constexpr bool ASM = (MODE == 3);  // register classes by hand: dK / dV accumulators and K / V fragments in AccVGPRs, scores / dP in VGPRs
   constexpr int RB = D * 2, T_BYTES = 64 * RB;          // Q, dO tiles of 64 queries
   constexpr int OFF_DO = T_BYTES, OFF_LSE = 2 * T_BYTES;  // + wave*512: [lse2 64 f32 | delta 64 f32]
   constexpr int STAGE = 2 * T_BYTES + 2048;
@@ -289,10 +358,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
   const int S = a.S;
   const int len = a.seqlens ? min(a.seqlens[b], S) : S;
   const int kv0 = kvblk * 128, kvw0 = kv0 + wave * 32, kvrow = kvw0 + l31;
-  uint16_t* outp = (DO_DK ? a.dk + ((int64_t)b * S + kvrow) * a.lddk : a.dv + ((int64_t)b * S + kvrow) * a.lddv) + (int64_t)h * D;
+  uint16_t* outk = a.dk + ((int64_t)b * S + kvrow) * a.lddk + (int64_t)h * D;
+  uint16_t* outv = a.dv + ((int64_t)b * S + kvrow) * a.lddv + (int64_t)h * D;
   if (kv0 >= len) {
     if (kvrow < S)
-      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) *(uint2*)(outp + d) = make_uint2(0, 0);
+      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) {
+        if constexpr (DO_DK) *(uint2*)(outk + d) = make_uint2(0, 0);
+        if constexpr (DO_DV) *(uint2*)(outv + d) = make_uint2(0, 0);
+      }
     return;
   }
   // K (and V) fragments of this wave's 32 keys: B operands
@@ -301,10 +374,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
     const int kr = min(kvrow, S - 1);
     const uint16_t* kp = a.k + ((int64_t)b * S + kr) * a.ldk + (int64_t)h * D + 8 * hi;
     const uint16_t* vp = a.v + ((int64_t)b * S + kr) * a.ldv + (int64_t)h * D + 8 * hi;
+    if constexpr (ASM) {  // into AccVGPRs: read only as MFMA B operands (the first tile's s_waitcnt vmcnt(0) covers them)
+      static_for<KSTEPS>([&](auto I) {
+        constexpr int ks = decltype(I)::value;
+        gload128_acc<32 * ks>(kf[ks], kp);
+        gload128_acc<32 * ks>(vf[ks], vp);
+      });
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      kf[ks] = *(const u32x4_t*)(kp + 16 * ks);
-      if constexpr (DO_DK) vf[ks] = *(const u32x4_t*)(vp + 16 * ks);
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        kf[ks] = *(const u32x4_t*)(kp + 16 * ks);
+        if constexpr (DO_DK) vf[ks] = *(const u32x4_t*)(vp + 16 * ks);
+      }
     }
   }
   const int q_begin = CAUSAL ? kv0 : 0;
@@ -321,11 +402,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
     glds4(lse_row + q0 + lane, base + OFF_LSE + wave * 512);
     glds4(dl_row + q0 + lane, base + OFF_LSE + wave * 512 + 256);
   };
-  f32x16_t acc[DBLK];
+  f32x16_t acck[DO_DK ? DBLK : 1], accv[DO_DV ? DBLK : 1];
 #pragma unroll
   for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (DO_DK) acck[i][r] = 0.f;
+      if constexpr (DO_DV) accv[i][r] = 0.f;
+    }
   const unsigned lds0 = lds_addr_of(smem);
   unsigned off_r[KSTEPS], off_t[KSTEPS];
   row_frag_offsets<D>(l31, hi, off_r);
@@ -341,14 +425,80 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
     __builtin_amdgcn_sched_barrier(0);
     if (j + 1 < ntiles) stage((j + 1) & 1, q0 + 64);
     const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
-    unsigned aq[KSTEPS], ado[KSTEPS], at[KSTEPS];
+    unsigned aq[KSTEPS], ado[KSTEPS], atq[DO_DK ? KSTEPS : 1], atdo[DO_DV ? KSTEPS : 1];
 #pragma unroll
     for (int i = 0; i < KSTEPS; ++i) {
       aq[i] = sb + off_r[i];
       ado[i] = sb + OFF_DO + off_r[i];
-      at[i] = sb + (DO_DK ? 0 : OFF_DO) + off_t[i];  // dK: Q^T from the Q tile; dV: dO^T from the dO tile
+      if constexpr (DO_DK) atq[i] = sb + off_t[i];            // dK: Q^T from the Q tile
+      if constexpr (DO_DV) atdo[i] = sb + OFF_DO + off_t[i];  // dV: dO^T from the dO tile
     }
     const unsigned al = sb + off_l;
+    if constexpr (MODE == 3 && !EDGE) {
+      // Full tile, one wave per SIMD: nothing else runs its VALU beside this wave's MFMAs, so the two 32-query halves are software-
+      // pipelined by hand.  A: S, dP of half 0 (two interleaved accumulate chains).  B: S, dP of half 1, with P = exp2(.) and
+      // dS = P o dP of half 0 sliced between its MFMAs.  C: dV, dK of half 0 (interleaved), with the element work of half 1 in
+      // between.  D: dV, dK of half 1.  Same products, operands and accumulation order as the sequential form: bit-identical.
+      f32x16_t sa[2], pa[2];
+      float pv[2][16], dsv[2][16];
+      u32x4_t pf[2][2], dsf[2][2];
+      auto sp = [&](auto HALF, auto&& slice) {
+        constexpr int hf = decltype(HALF)::value;
+        u32x4_t lsev[4], dlv[4];
+        static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<hf * 128 + 32 * g>(lsev[g], al); });
+        static_for<4>([&](auto I) { constexpr int g = decltype(I)::value; lds_read128<256 + hf * 128 + 32 * g>(dlv[g], al); });
+        stream_row_frags2<hf * 32 * RB, hf * 32 * RB + OFF_DO, KSTEPS>(aq, [&](auto I, const u32x4_t& fr) {
+          constexpr int n = decltype(I)::value;
+          if constexpr (n == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                sa[hf][4 * g + e] = __uint_as_float(lsev[g][e]);
+                pa[hf][4 * g + e] = __uint_as_float(dlv[g][e]);
+              }
+          }
+          if constexpr (n == 0) mfma_ready(sa[hf], pa[hf]);
+          if constexpr (n % 2 == 0) mfma32va<DT>(sa[hf], fr, kf[n / 2]);
+          else mfma32va<DT>(pa[hf], fr, vf[n / 2]);
+          slice(I);
+        });
+        mfma_settle(sa[hf], pa[hf]);
+      };
+      constexpr int EPS = 16 / (2 * KSTEPS);  // elements per slice: both streams have 2 * KSTEPS = 4 * DBLK fragments
+      static_assert(EPS * 2 * KSTEPS == 16 && 4 * DBLK == 2 * KSTEPS, "slices cover the 16 accumulator elements");
+      auto elem = [&](auto HALF, auto I) {  // slice I of half HALF: P and dS of EPS elements
+        constexpr int hf = decltype(HALF)::value;
+#pragma unroll
+        for (int r = decltype(I)::value * EPS; r < (decltype(I)::value + 1) * EPS; ++r) {
+          pv[hf][r] = fast_exp2(sa[hf][r] * sc);
+          dsv[hf][r] = pv[hf][r] * pa[hf][r];
+        }
+      };
+      auto packs = [&](auto HALF) {
+        constexpr int hf = decltype(HALF)::value;
+        pf[hf][0] = pack8v<DT>(pv[hf]); pf[hf][1] = pack8v<DT>(pv[hf] + 8);
+        dsf[hf][0] = pack8v<DT>(dsv[hf]); dsf[hf][1] = pack8v<DT>(dsv[hf] + 8);
+      };
+      auto dvdk = [&](auto HALF, auto&& slice) {
+        constexpr int hf = decltype(HALF)::value;
+        stream_tr_frags2<RB, hf * 32, OFF_DO, 0, 2 * DBLK>(atq, [&](auto I, const u32x4_t& fr) {
+          constexpr int g = decltype(I)::value, f = g / 2;
+          if constexpr (g % 2 == 0) mfma32a<DT>(accv[f / 2], fr, pf[hf][f % 2]);
+          else mfma32a<DT>(acck[f / 2], fr, dsf[hf][f % 2]);
+          slice(I);
+        });
+      };
+      using H0 = std::integral_constant<int, 0>;
+      using H1 = std::integral_constant<int, 1>;
+      sp(H0{}, [&](auto) {});
+      sp(H1{}, [&](auto I) { elem(H0{}, I); });
+      packs(H0{});
+      dvdk(H0{}, [&](auto I) { elem(H1{}, I); });
+      packs(H1{});
+      dvdk(H1{}, [&](auto) {});
+      return;
+    }
     static_for<2>([&](auto HALF) {
       constexpr int hf = decltype(HALF)::value;
       const int qh = q0 + 32 * hf;
@@ -368,7 +518,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) sacc[4 * g + e] = __uint_as_float(lsev[g][e]);
         }
-        sacc = mfma32v<DT>(fr, kf[decltype(I)::value], sacc);
+        if constexpr (ASM) {
+          if constexpr (decltype(I)::value == 0) mfma_ready(sacc, sacc);
+          mfma32va<DT>(sacc, fr, kf[decltype(I)::value]);
+        } else {
+          sacc = mfma32v<DT>(fr, kf[decltype(I)::value], sacc);
+        }
       });
       if constexpr (DO_DK) {
         u32x4_t dlv[4];
@@ -380,9 +535,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) pacc[4 * g + e] = __uint_as_float(dlv[g][e]);
           }
-          pacc = mfma32v<DT>(fr, vf[decltype(I)::value], pacc);
+          if constexpr (ASM) {
+            if constexpr (decltype(I)::value == 0) mfma_ready(pacc, pacc);
+            mfma32va<DT>(pacc, fr, vf[decltype(I)::value]);
+          } else {
+            pacc = mfma32v<DT>(fr, vf[decltype(I)::value], pacc);
+          }
         });
       }
+      if constexpr (ASM) mfma_settle(sacc, pacc);
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) pv[r] = fast_exp2(sacc[r] * sc);
@@ -394,15 +555,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
           pv[r] = ok ? pv[r] : 0.f;
         }
       }
+      if constexpr (DO_DV) {
+        const u32x4_t pf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
+        stream_tr_frags<RB, hf * 32, 2 * DBLK>(atdo, [&](auto I, const u32x4_t& fr) {
+          constexpr int f = decltype(I)::value;
+          if constexpr (ASM) mfma32a<DT>(accv[f / 2], fr, pf[f % 2]);
+          else accv[f / 2] = mfma32v<DT>(fr, pf[f % 2], accv[f / 2]);
+        });
+      }
       if constexpr (DO_DK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) pv[r] *= pacc[r];  // dS (unscaled)
+        const u32x4_t dsf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
+        stream_tr_frags<RB, hf * 32, 2 * DBLK>(atq, [&](auto I, const u32x4_t& fr) {
+          constexpr int f = decltype(I)::value;
+          if constexpr (ASM) mfma32a<DT>(acck[f / 2], fr, dsf[f % 2]);
+          else acck[f / 2] = mfma32v<DT>(fr, dsf[f % 2], acck[f / 2]);
+        });
       }
-      const u32x4_t pf[2] = {pack8v<DT>(pv), pack8v<DT>(pv + 8)};
-      stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
-        constexpr int f = decltype(I)::value;
-        acc[f / 2] = mfma32v<DT>(fr, pf[f % 2], acc[f / 2]);
-      });
     });
   };
   // tiles: diagonal tiles first (j < n_diag), then fully visible ones, then the tail at the sequence end
@@ -415,27 +585,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kv_k(Bwd2Args a) {
   for (int j = n_diag; j < j_full_end; ++j) tile(j, std::false_type{});
   for (int j = max(n_diag, j_full_end); j < ntiles; ++j) tile(j, std::true_type{});
 
+  if constexpr (ASM) {
+#pragma unroll
+    for (int i = 0; i < DBLK; ++i) { mfma_settle_acc(accv[i]); mfma_settle_acc(acck[i]); }
+  }
   if (kvrow < S) {
     const bool valid = kvrow < len;
+    auto store_rows = [&](auto& acc, uint16_t* outp) {
+#pragma unroll
+      for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * i + 8 * g + 4 * hi;
+          uint2 w = make_uint2(0, 0);
+          if (valid)
+            w = make_uint2(pack2<DT>(acc[i][4 * g + 0], acc[i][4 * g + 1]), pack2<DT>(acc[i][4 * g + 2], acc[i][4 * g + 3]));
+          *(uint2*)(outp + d) = w;
+        }
+    };
+    if constexpr (DO_DV) store_rows(accv, outv);
     if constexpr (DO_DK) {
 #pragma unroll
       for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] *= a.scale;
-      if (a.rope && valid) unrope_rows<D>(acc, a.rope + (int64_t)kvrow * (D / 2), hi);
+        for (int r = 0; r < 16; ++r) acck[i][r] *= a.scale;
+      if (a.rope && valid) unrope_rows<D>(acck, a.rope + (int64_t)kvrow * (D / 2), hi);
+      store_rows(acck, outk);
     }
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * i + 8 * g + 4 * hi;
-        uint2 w = make_uint2(0, 0);
-        if (valid)
-          w = make_uint2(pack2<DT>(acc[i][4 * g + 0], acc[i][4 * g + 1]), pack2<DT>(acc[i][4 * g + 2], acc[i][4 * g + 3]));
-        *(uint2*)(outp + d) = w;
-      }
   }
 }
+
+// dK + dV in one kernel (S and dP computed once per tile: 4 instead of 5 products for the pair); A-B switch mh_attn_bwd_fused_kv
+int g_attn_bwd_fused_kv = 1;
 
 template <int DT, int D, bool CAUSAL>
 int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
@@ -445,20 +626,27 @@ int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
     hipFuncSetAttribute((const void*)attn_bwd2_dq_k<DT, D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsQ);
     hipFuncSetAttribute((const void*)attn_bwd2_kv_k<DT, D, CAUSAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsKV);
     hipFuncSetAttribute((const void*)attn_bwd2_kv_k<DT, D, CAUSAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsKV);
+    hipFuncSetAttribute((const void*)attn_bwd2_kv_k<DT, D, CAUSAL, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsKV);
     attr = true;
   }
   const int64_t nth = (int64_t)a.B * a.S * a.H;
   constexpr int RPB = 256 / (D / 8);
   hipLaunchKernelGGL((delta2_k<DT, D>), dim3((unsigned)((nth + RPB - 1) / RPB)), dim3(256), 0, st, a);
   dim3 grid(xcd_grid(a.B * a.H, (a.S + 127) / 128));
-  hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 1>), grid, dim3(256), ldsKV, st, a);
-  hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 2>), grid, dim3(256), ldsKV, st, a);
+  if (g_attn_bwd_fused_kv && D == 128) {  // (D = 64, the vision tower's 577-token sequences: measured slower fused, 0.48 vs 0.40 ms)
+    hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 3>), grid, dim3(256), ldsKV, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 1>), grid, dim3(256), ldsKV, st, a);
+    hipLaunchKernelGGL((attn_bwd2_kv_k<DT, D, CAUSAL, 2>), grid, dim3(256), ldsKV, st, a);
+  }
   hipLaunchKernelGGL((attn_bwd2_dq_k<DT, D, CAUSAL>), grid, dim3(256), ldsQ, st, a);
   MH_LAUNCH_CHECK();
 }
 
 }  // namespace
 }  // namespace mhattn
+
+extern "C" void mh_attn_bwd_fused_kv(int on) { mhattn::g_attn_bwd_fused_kv = on ? 1 : 0; }
 
 extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                             int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq,

@@ -917,6 +917,11 @@ def gemv_mfma_wide(on: bool):
     L.lib().mh_gemv_mfma_wide(i32(1 if on else 0))
 
 
+def attn_bwd_fused_kv(on: bool):
+    """A/B switch: dK and dV of the attention backward from one kernel (default) or two."""
+    L.lib().mh_attn_bwd_fused_kv(i32(int(on)))
+
+
 def gemm_raster_group(gm: int):
     """A/B switch: tile rows per raster group of the MFMA GEMM kernels (default 4)."""
     L.lib().mh_gemm_raster_group(i32(gm))

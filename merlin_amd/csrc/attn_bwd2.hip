@@ -154,7 +154,10 @@ __device__ __forceinline__ void stream_row_frags2(const unsigned* addr, F&& cons
 // The same for transposed fragments: stream element g = (tile g % 2, fragment g / 2), fragment f = (d-block f / 2, k-step f % 2).
 template <int RB, int R0, int OFF0, int OFF1, int NFH, typename F>
 __device__ __forceinline__ void stream_tr_frags2(const unsigned* addr, F&& consume) {
-  constexpr int NF = 2 * NFH, W = 4;
+#ifndef MH_TR_WINDOW
+#define MH_TR_WINDOW 4  // fragments in flight (2 reads each; the lgkm counter holds 15)
+#endif
+  constexpr int NF = 2 * NFH, W = MH_TR_WINDOW;
   u32x2_t w[2 * W];
   auto issue = [&](auto G, auto SLOT) {
     constexpr int g = decltype(G)::value, sl = decltype(SLOT)::value, f = g / 2, off = (g % 2) ? OFF1 : OFF0;
@@ -394,10 +397,16 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
   const uint16_t* dobase = a.dout + (int64_t)b * S * a.lddo + (int64_t)h * D;
   const float* lse_row = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
   const float* dl_row = a.delta + ((int64_t)b * a.H + h) * a.S_pad;
+  const auto so_q = stage_offsets<D, 64>(a.ldq, tid), so_do = stage_offsets<D, 64>(a.lddo, tid);
   auto stage = [&](int s, int q0) {
     char* base = smem + s * STAGE;
-    stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave);
-    stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave);
+    if constexpr (MODE == 2) {
+      stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave);
+      stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave);
+    } else {
+      stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave, so_q);
+      stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave, so_do);
+    }
     // per-wave copy: lanes 0-63 -> lse2[q0 + lane], then delta[q0 + lane] (2 x 256 contiguous LDS bytes)
     glds4(lse_row + q0 + lane, base + OFF_LSE + wave * 512);
     glds4(dl_row + q0 + lane, base + OFF_LSE + wave * 512 + 256);

@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   }
   const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
   const uint16_t* vbase = a.v + (int64_t)b * S * a.ldv + (int64_t)h * D;
+  const auto so_k = stage_offsets<D, 64>(a.ldk, tid), so_v = stage_offsets<D, 64>(a.ldv, tid);
   auto stage = [&](int s, int kv0) {
     char* base = smem + s * STAGE;
-    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave);
-    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave);
+    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave, so_k);
+    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave, so_v);
   };
 
   f32x16_t o[DBLK];

@@ -74,6 +74,28 @@ __device__ __forceinline__ void tr_frag_offsets(int lane, unsigned (&off)[D / 16
 
 // global_load_lds of one [ROWS][D] row-major tile: gbase points at (row 0, col 0) of the tile for this (b,h);
 // row r of the tile is at gbase + min(r0 + r, rmax) * ld.  256 threads, wave-uniform LDS destination.
+// Tiles that lie wholly inside the sequence (all but the last one) need no clamp: their addresses are a wave-uniform tile base
+// (scalar arithmetic) plus per-thread byte offsets that do not depend on the tile - stage_offsets() computes those once per
+// kernel.  Computed per tile, the clamped form cost 16 v_mul_lo_u32 + 8 v_mad_u64_u32 (quarter-rate) and ~45 more integer VALU
+// instructions per K|V tile, a quarter of the forward kernel's VALU work.
+template <int D, int ROWS>
+struct StageOffs {
+  unsigned off[ROWS * (D / 8) / 256];
+};
+template <int D, int ROWS>
+__device__ __forceinline__ StageOffs<D, ROWS> stage_offsets(int64_t ld, int tid) {
+  constexpr int CPR = D / 8;
+  constexpr int NLD = ROWS * CPR / 256;
+  StageOffs<D, ROWS> o;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int qd = i * 256 + tid;
+    const int row = qd / CPR, cc = qd % CPR;
+    const int c = cc ^ TileSwz<D>::f(row);
+    o.off[i] = ((unsigned)row * (unsigned)ld + (unsigned)(c * 8)) * 2u;  // bytes; < 2^31 for any row stride this library accepts
+  }
+  return o;
+}
 template <int D, int ROWS>
 __device__ __forceinline__ void stage_rows(const uint16_t* gbase, int64_t ld, int r0, int rmax, char* lds_tile, int tid, int wave) {
   constexpr int CPR = D / 8;
@@ -85,6 +107,21 @@ __device__ __forceinline__ void stage_rows(const uint16_t* gbase, int64_t ld, in
     const int c = cc ^ TileSwz<D>::f(row);
     glds16(gbase + (int64_t)min(r0 + row, rmax) * ld + c * 8, lds_tile + (i * 256 + wave * 64) * 16);
   }
+}
+// (the kernels with registers to spare - not the dQ and the stand-alone dK kernel, at 251 / 256 VGPRs - use this form)
+template <int D, int ROWS>
+__device__ __forceinline__ void stage_rows(const uint16_t* gbase, int64_t ld, int r0, int rmax, char* lds_tile, int tid, int wave,
+                                           const StageOffs<D, ROWS>& so) {
+  constexpr int NLD = ROWS * (D / 8) / 256;
+#ifndef MH_STAGE_CLAMPED_ONLY  // (development A/B: build with -DMH_STAGE_CLAMPED_ONLY for the per-tile address arithmetic everywhere)
+  if (r0 + ROWS - 1 <= rmax) {  // wave-uniform
+    const char* tb = (const char*)(gbase + (int64_t)r0 * ld);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) glds16(tb + so.off[i], lds_tile + (i * 256 + wave * 64) * 16);
+    return;
+  }
+#endif
+  stage_rows<D, ROWS>(gbase, ld, r0, rmax, lds_tile, tid, wave);
 }
 
 }  // namespace mhattn

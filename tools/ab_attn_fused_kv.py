@@ -36,6 +36,8 @@ for (B, S, H, D, causal, lens) in ((8, 4096, 32, 128, True, None), (4, 8192, 32,
     sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
     o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=sl)
     do = torch.randn(B * S, H * D, device=dev).to(torch.bfloat16)
+    fw = lambda: O.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=sl, out=o, lse=lse)
+    print(f"   forward: cold {timeit(fw):.3f} hot {timeit(fw, hot=True):.3f} ms", flush=True)
     res, tc, th = {}, {}, {}
     for m in MODES + MODES:
         O.attn_bwd_fused_kv(m)

@@ -73,6 +73,12 @@ def test_attention_at_benchmark_sequence_lengths(dtype, B, S, H, D, causal, lens
     assert _relerr(dk[sl].view(nb, S, H, D), rk) < tol, "dk"
     assert _relerr(dq[sl].view(nb, S, H, D), rq) < tol, "dq"
     assert torch.isfinite(o.float()).all() and torch.isfinite(dq.float()).all()
+    try:  # the fused dK + dV kernel (default at D = 128) against the two single-output kernels: bit for bit
+        O.attn_bwd_fused_kv(False)
+        dq2, dk2, dv2 = O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=lt if lens else None)
+    finally:
+        O.attn_bwd_fused_kv(True)
+    assert torch.equal(dk2, dk) and torch.equal(dv2, dv) and torch.equal(dq2, dq)
 
 
 def _sample_tiles(M, N, n=6, t=96, seed=0):

@@ -269,6 +269,14 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     # the delta/lse scratch is reused across calls: a second call (other data) must not see stale rows
     dq3, dk3, dv3 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
     assert torch.equal(dq3, dq2) and torch.equal(dk3, dk2) and torch.equal(dv3, dv2)
+    # dK + dV from one kernel (default at D = 128: scores / dP once per tile, hand-pipelined halves, asm MFMAs) = the two single-output
+    # kernels bit for bit - same products, operands and accumulation order
+    try:
+        ops.attn_bwd_fused_kv(False)
+        dq4, dk4, dv4 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    finally:
+        ops.attn_bwd_fused_kv(True)
+    assert torch.equal(dq4, dq2) and torch.equal(dk4, dk2) and torch.equal(dv4, dv2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -117,6 +117,37 @@ __device__ __forceinline__ f32x4_t mfma_f8(const u32x4& a0, const u32x4& a1, con
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, 127);
 }
 __device__ __forceinline__ void lds_read_u8(unsigned& d, unsigned addr) { asm volatile("ds_read_u8 %0, %1" : "=v"(d) : "v"(addr)); }
+#ifdef MH_GEMM_MFMA32_SPEEDTEST
+// SPEED PROBE ONLY (wrong results): the same fragments, registers and issue slots, but 8 32x32x16 MFMAs per quad instead of 16
+// 16x16x32 - what the main loop would run at with the wider instruction (tools/probes/mfma_probe.py: a lone 16x16x32 stream tops out
+// at 91 % of peak with two waves per SIMD, 32x32x16 at 99 %).
+typedef float f32x16p_t __attribute__((ext_vector_type(16)));
+#define MFMA_QUAD_16(MH, NH, bf)                                                            \
+  do {                                                                                      \
+    f32x16p_t q0_, q1_;                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+      q0_[e] = acc[MH][0][NH][0][e]; q0_[4 + e] = acc[MH][0][NH][1][e]; q0_[8 + e] = acc[MH][1][NH][0][e]; q0_[12 + e] = acc[MH][1][NH][1][e]; \
+      q1_[e] = acc[MH][2][NH][0][e]; q1_[4 + e] = acc[MH][2][NH][1][e]; q1_[8 + e] = acc[MH][3][NH][0][e]; q1_[12 + e] = acc[MH][3][NH][1][e]; \
+    }                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+        q0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[j][ks]), __builtin_bit_cast(bf16x8_t, af[2 * j][ks]), q0_, 0, 0, 0);     \
+        q1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[j][ks]), __builtin_bit_cast(bf16x8_t, af[2 * j + 1][ks]), q1_, 0, 0, 0); \
+      }                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+      acc[MH][0][NH][0][e] = q0_[e]; acc[MH][0][NH][1][e] = q0_[4 + e]; acc[MH][1][NH][0][e] = q0_[8 + e]; acc[MH][1][NH][1][e] = q0_[12 + e]; \
+      acc[MH][2][NH][0][e] = q1_[e]; acc[MH][2][NH][1][e] = q1_[4 + e]; acc[MH][3][NH][0][e] = q1_[8 + e]; acc[MH][3][NH][1][e] = q1_[12 + e]; \
+    }                                                                                       \
+  } while (0)
+#else
+#define MFMA_QUAD_16(MH, NH, bf)                                                            \
+  do {                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+          acc[MH][i][NH][j] = mfma16v<DT>(bf[j][ks], af[i][ks], acc[MH][i][NH][j]);         \
+  } while (0)
+#endif
 #define MFMA_QUAD(MH, NH, bf)                                                               \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
@@ -125,10 +156,7 @@ __device__ __forceinline__ void lds_read_u8(unsigned& d, unsigned addr) { asm vo
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
           acc[MH][i][NH][j] = mfma_f8(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[MH][i][NH][j], ESC ? esc[NH][j] : 127); \
     } else {                                                                                \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                     \
-            acc[MH][i][NH][j] = mfma16v<DT>(bf[j][ks], af[i][ks], acc[MH][i][NH][j]);       \
+      MFMA_QUAD_16(MH, NH, bf);                                                             \
     }                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)

@@ -1,0 +1,40 @@
+// Sustained bf16 MFMA rate of one MI355X with NO memory traffic: every wave loops over 16 independent 16x16x32 accumulate chains on
+// constant operands.  What the matrix pipes deliver once the chip has settled under its power cap - the ceiling any GEMM main loop is under.
+// hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/mfma_probe.hip -o tools/probes/mfma_probe.so ; python tools/probes/mfma_probe.py
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_k(float* __restrict__ sink, int iters, float seed) {
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + threadIdx.x * 1e-3f + i); b[i] = (__bf16)(seed - i * 0.5f); }
+  float s = 0.f;
+  if constexpr (SHAPE == 16) {
+    f32x4_t acc[16];
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    for (int j = 0; j < 16; ++j) s += acc[j][0] + acc[j][3];
+  } else {
+    f32x16_t acc[4];
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15];
+  }
+  if (s == 12345.678f) sink[blockIdx.x] = s;
+}
+
+// flops per launch = blocks * 4 waves * iters * (16 * 16x16x32x2  |  4 * 32x32x16x2)
+extern "C" int mfma_run(void* sink, int blocks, int iters, int shape, void* stream) {
+  if (shape == 16) hipLaunchKernelGGL(mfma_k<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
+  else hipLaunchKernelGGL(mfma_k<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
+  return (int)hipGetLastError();
+}

@@ -423,7 +423,8 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   if (g_force_kernel == 128) big = false;
   if (g_force_kernel == 256) big = true;
 #ifdef MH_DEV_ARMS  // alternative tilings kept for A/B timing (tools/dev_arms/): compiled only into the dev library
-  if (g_force_kernel == 32 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arm: MFMA 32x32x16 fragments
+  if ((g_force_kernel == 32 || g_force_kernel == 33) && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode) {  // A/B arms: MFMA 32x32x16 fragments (33: two phases per K-tile)
+    g_m32_kcut = g_force_kernel == 33;
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));

@@ -234,5 +234,6 @@ int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0
 int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA
 int launch_gemm_nt_w8(const GemmArgs& g, int dt, hipStream_t stream);      // gemm256w8.hip (8 waves, dense asm stream)
 int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)
+extern int g_m32_kcut;
 
 }  // namespace mhgemm

@@ -268,6 +268,12 @@ def main():
                      "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r02_gemm_traffic.json)", "launches": n,
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
     }
+    if not fp8_dom:
+        sustained = sustained_mfma_tflops()
+        if sustained:
+            line["roofline"]["sustained_mfma_probe"] = {"tflops": round(sustained, 1), "frac_of_it": round(ach / sustained, 4),
+                                                        "what": "register-only bf16 32x32x16 MFMA loop on pseudo-random operands, no memory traffic, this GPU, just now "
+                                                                "(tools/probes/mfma_probe.hip): what the matrix pipes sustain under the power cap"}
     if fwd_ms is not None:
         line["forward_only"] = {"ms_per_step": round(fwd_ms, 2), "tokens_per_s_per_gpu": round(n_tok / (fwd_ms * 1e-3), 1),
                                 "useful_tflops_per_gpu": round(fwd / (fwd_ms * 1e-3) / 1e12, 1),
@@ -280,6 +286,32 @@ def main():
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def sustained_mfma_tflops():
+    """Median of three ~30 ms launches of the register-only MFMA loop (None if the probe library is not built)."""
+    import ctypes
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "probes", "mfma_probe.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        sink = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+        blocks, iters, per_iter = 512, 100000, 8 * 32 * 32 * 16 * 2
+        st = torch.cuda.current_stream().cuda_stream
+        rates = []
+        for i in range(4):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            lib.mfma_run(ctypes.c_void_p(sink.data_ptr()), blocks, iters, 32, 1, ctypes.c_void_p(st))
+            e.record()
+            torch.cuda.synchronize()
+            if i:
+                rates.append(blocks * 4 * iters * per_iter / (s.elapsed_time(e) * 1e-3) / 1e12)
+        return sorted(rates)[1]
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

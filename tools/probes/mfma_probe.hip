@@ -7,17 +7,26 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
 
-template <int SHAPE>
+template <int SHAPE, bool RND>
 __global__ __launch_bounds__(256) void mfma_k(float* __restrict__ sink, int iters, float seed) {
-  bf16x8_t a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + threadIdx.x * 1e-3f + i); b[i] = (__bf16)(seed - i * 0.5f); }
+  // 8 different operand pairs, used in rotation: RND = pseudo-random bit patterns (operand buses toggle as in a real GEMM), else near-constant
+  bf16x8_t av[8], bv[8];
+  unsigned st = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u) ^ 0x9e3779b9u;
+  for (int q = 0; q < 8; ++q)
+    for (int i = 0; i < 8; ++i) {
+      st = st * 1664525u + 1013904223u;
+      const float ra = RND ? ((int)(st >> 9) - (1 << 22)) * (1.0f / (1 << 20)) : seed + threadIdx.x * 1e-3f + i;
+      st = st * 1664525u + 1013904223u;
+      const float rb = RND ? ((int)(st >> 9) - (1 << 22)) * (1.0f / (1 << 20)) : seed - i * 0.5f;
+      av[q][i] = (__bf16)ra; bv[q][i] = (__bf16)rb;
+    }
   float s = 0.f;
   if constexpr (SHAPE == 16) {
     f32x4_t acc[16];
     for (int j = 0; j < 16; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+      for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[j & 7], bv[(j + 3) & 7], acc[j], 0, 0, 0);
     }
     for (int j = 0; j < 16; ++j) s += acc[j][0] + acc[j][3];
   } else {
@@ -25,16 +34,19 @@ __global__ __launch_bounds__(256) void mfma_k(float* __restrict__ sink, int iter
     for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j], bv[(j + 3) & 7], acc[j & 3], 0, 0, 0);
     }
     for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15];
   }
   if (s == 12345.678f) sink[blockIdx.x] = s;
 }
 
-// flops per launch = blocks * 4 waves * iters * (16 * 16x16x32x2  |  4 * 32x32x16x2)
-extern "C" int mfma_run(void* sink, int blocks, int iters, int shape, void* stream) {
-  if (shape == 16) hipLaunchKernelGGL(mfma_k<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
-  else hipLaunchKernelGGL(mfma_k<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
+// flops per launch = blocks * 4 waves * iters * (16 * 16x16x32x2  |  8 * 32x32x16x2)
+extern "C" int mfma_run(void* sink, int blocks, int iters, int shape, int rnd, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (shape == 16 && rnd) hipLaunchKernelGGL((mfma_k<16, true>), dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 1.0f);
+  else if (shape == 16) hipLaunchKernelGGL((mfma_k<16, false>), dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 1.0f);
+  else if (rnd) hipLaunchKernelGGL((mfma_k<32, true>), dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 1.0f);
+  else hipLaunchKernelGGL((mfma_k<32, false>), dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 1.0f);
   return (int)hipGetLastError();
 }

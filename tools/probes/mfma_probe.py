@@ -5,11 +5,11 @@ lib = ctypes.CDLL(os.path.join(here, "mfma_probe.so"))
 dev = torch.device("cuda:0")
 sink = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-for shape, per_iter in ((16, 16 * 16 * 16 * 32 * 2), (32, 4 * 32 * 32 * 16 * 2)):
+for shape, per_iter, rnd in ((16, 16 * 16 * 16 * 32 * 2, 0), (32, 8 * 32 * 32 * 16 * 2, 0), (16, 16 * 16 * 16 * 32 * 2, 1), (32, 8 * 32 * 32 * 16 * 2, 1)):
     for wpc in (4, 8):  # waves per CU
         blocks = 256 * wpc // 4
-        iters = 400000 if wpc == 4 else 200000
-        run = lambda: lib.mfma_run(ctypes.c_void_p(sink.data_ptr()), blocks, iters, shape, ctypes.c_void_p(st))
+        iters = (400000 if wpc == 4 else 200000) // (2 if shape == 32 else 1)
+        run = lambda: lib.mfma_run(ctypes.c_void_p(sink.data_ptr()), blocks, iters, shape, rnd, ctypes.c_void_p(st))
         run(); torch.cuda.synchronize()
         rates = []
         for rep in range(12):
@@ -17,4 +17,4 @@ for shape, per_iter in ((16, 16 * 16 * 16 * 32 * 2), (32, 4 * 32 * 32 * 16 * 2))
             s.record(); run(); e.record(); torch.cuda.synchronize()
             t = s.elapsed_time(e) * 1e-3
             rates.append(blocks * 4 * iters * per_iter / t / 1e12)
-        print(f"mfma {shape}x{shape}, {wpc} waves/CU: launch {t * 1e3:.0f} ms; TFLOP/s per launch: " + " ".join(f"{r:.0f}" for r in rates), flush=True)
+        print(f"mfma {shape}x{shape} {'random' if rnd else 'constant'} operands, {wpc} waves/CU: launch {t * 1e3:.0f} ms; TFLOP/s per launch: " + " ".join(f"{r:.0f}" for r in rates), flush=True)

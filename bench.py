@@ -278,7 +278,7 @@ def main():
         line["forward_only"] = {"ms_per_step": round(fwd_ms, 2), "tokens_per_s_per_gpu": round(n_tok / (fwd_ms * 1e-3), 1),
                                 "useful_tflops_per_gpu": round(fwd / (fwd_ms * 1e-3) / 1e12, 1),
                                 "mfma_roofline_frac": round(fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # (the reported CPU baseline belongs to the N = 1 line only)
         try:
             line["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # the baseline leg must never take the GPU number down

@@ -138,9 +138,12 @@ __device__ __forceinline__ void gload128_acc(u32x4_t& d, const void* ptr) {
 
 // Two row-fragment streams interleaved (fragment n: tile at +OFF0 for even n, +OFF1 for odd n, k-step n / 2): two independent MFMA
 // chains alternate, so neither waits for its own previous accumulate.  consume(n, frag) may also carry a slice of VALU work.
+#ifndef MH_SP_WINDOW
+#define MH_SP_WINDOW 6  // + the 8 lse / delta reads issued just before the stream: 14 LDS requests in flight (the lgkm counter holds 15; measured 6 < 7 ~ 8)
+#endif
 template <int OFF0, int OFF1, int KS, typename F>
 __device__ __forceinline__ void stream_row_frags2(const unsigned* addr, F&& consume) {
-  constexpr int NF = 2 * KS, W = 8;
+  constexpr int NF = 2 * KS, W = NF < MH_SP_WINDOW ? NF : MH_SP_WINDOW;
   u32x4_t w[W];
   static_for<W>([&](auto I) { constexpr int n = decltype(I)::value; lds_read128<(n % 2) ? OFF1 : OFF0>(w[n], addr[n / 2]); });
   static_for<NF>([&](auto I) {

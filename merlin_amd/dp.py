@@ -40,7 +40,8 @@ class GradSync:
         self.bytes = 0
         self.order = []  # bucket (offset, numel) sequence of the last synced backward (tests compare it across ranks)
         self._sync = True
-        self._reduced = False  # the gradient arena holds all-reduced sums (until the next fresh backward)
+        self._reduced = False  # the gradient arena holds all-reduced sums (until the next fresh backward / optimizer step)
+        self._reduced_at = None  # engine.weight_version when they were reduced
         engine.on_grads_ready = self._on_ready
         engine.on_backward_begin = self._on_begin
 
@@ -61,8 +62,23 @@ class GradSync:
         return self.no_sync()
 
     # ---- engine callbacks -----------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True):
+        """Zero (or detach) the model's gradients and forget that they were reduced.  `optimizer.zero_grad(set_to_none=False)`
+        / `model.zero_grad(set_to_none=False)` leave `.grad` attached, which the arena cannot tell from accumulated values;
+        an optimizer step in between (the weights changed since the reduce) is recognised on its own, this call covers the
+        rest (e.g. a skipped step after an overflow)."""
+        for p in self.engine.arena.params.values():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+        self._reduced = False
+
     def _on_begin(self, fresh: bool):
-        if fresh:
+        if fresh or (self._reduced and self._reduced_at != self.engine.weight_version):
+            # fresh gradients, or an optimizer stepped since the reduce (FusedAdamW bumps weight_version; a stock torch optimizer
+            # is seen through the parameters' version counters at the next forward): the window that was reduced is over
             self._reduced = False
         elif self._reduced and self.active:
             raise RuntimeError("merlin_amd.dp: this backward accumulates onto gradients that were already all-reduced; run all "
@@ -77,6 +93,7 @@ class GradSync:
         if names is None:  # end of backward: join the communication stream
             self.finish()
             self._reduced = True
+            self._reduced_at = self.engine.weight_version
             return
         names = [n for n in names if A.params[n].requires_grad]
         if not names:

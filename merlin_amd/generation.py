@@ -65,15 +65,55 @@ def _resolve_lengths(prompt_len, max_new_tokens, max_length):
     return max(prompt_len + 1, 20)  # HF GenerationConfig default max_length = 20
 
 
+# decoding options this module implements, with transformers' GenerationConfig defaults
+_DEFAULTS = dict(max_new_tokens=None, max_length=None, eos_token_id=None, pad_token_id=None, do_sample=False, temperature=1.0, top_k=50,
+                 top_p=1.0, num_beams=1, length_penalty=1.0, early_stopping=False, use_cache=True)
+# options that are accepted only at the value that leaves the implemented modes unchanged (anything else is a decoding mode the
+# reference's scripts never reach: refuse it instead of silently returning something different)
+_NEUTRAL = dict(repetition_penalty=(1.0, None), no_repeat_ngram_size=(0, None), num_return_sequences=(1, None), num_beam_groups=(1, None),
+                penalty_alpha=(None, 0.0), typical_p=(1.0, None), min_new_tokens=(None, 0), min_length=(0, None), bad_words_ids=(None,),
+                return_dict_in_generate=(False, None), output_scores=(False, None), output_logits=(False, None),
+                output_attentions=(False, None), output_hidden_states=(False, None), logits_processor=(None,), prefix_allowed_tokens_fn=(None,),
+                encoder_no_repeat_ngram_size=(0, None), diversity_penalty=(0.0, None), epsilon_cutoff=(0.0, None), eta_cutoff=(0.0, None),
+                min_p=(None,), renormalize_logits=(False, None), forced_bos_token_id=(None,), forced_eos_token_id=(None,),
+                suppress_tokens=(None,), begin_suppress_tokens=(None,), assistant_model=(None,), synced_gpus=(False, None),
+                bos_token_id=None, use_beam_search=None, negative_prompt_ids=(None,), num_assistant_tokens=None, trust_remote_code=None)
+
+
+def _resolve_options(generation_config, kw):
+    """HF precedence: GenerationConfig fields first, explicit keyword arguments over them; unknown names raise TypeError."""
+    opt = dict(_DEFAULTS)
+    if generation_config is not None:
+        for k in list(_DEFAULTS) + list(_NEUTRAL):
+            v = getattr(generation_config, k, None)
+            if v is None:
+                continue
+            if k in _DEFAULTS:
+                opt[k] = v
+            elif _NEUTRAL[k] is not None and v not in _NEUTRAL[k] and v != []:
+                raise NotImplementedError(f"generation_config.{k}={v!r} is not part of the decoding modes the reference's eval scripts use")
+    for k, v in kw.items():
+        if k in _DEFAULTS:
+            opt[k] = _DEFAULTS[k] if v is None and k not in ("max_new_tokens", "max_length", "eos_token_id", "pad_token_id") else v
+        elif k in _NEUTRAL:
+            ok = _NEUTRAL[k]
+            if ok is not None and v not in ok and v != []:
+                raise NotImplementedError(f"generate({k}={v!r}) is not part of the decoding modes the reference's eval scripts use")
+        else:
+            raise TypeError(f"generate() got an unexpected keyword argument '{k}'")
+    return opt
+
+
 @torch.no_grad()
-def generate(model, input_ids, images=None, attention_mask=None, max_new_tokens=None, max_length=None, eos_token_id=None,
-             pad_token_id=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0, num_beams=1, length_penalty=1.0,
-             early_stopping=False, stopping_criteria=None, use_cache=True, use_graph=True, fp8_weights=False, seed=None,
-             **unused):
-    for k, default in (("repetition_penalty", 1.0), ("no_repeat_ngram_size", 0), ("num_return_sequences", 1), ("num_beam_groups", 1),
-                       ("penalty_alpha", None), ("typical_p", 1.0), ("min_new_tokens", None), ("bad_words_ids", None)):
-        if unused.get(k, default) not in (default, None):
-            raise NotImplementedError(f"generate({k}=...) is not part of the decoding modes the reference's eval scripts use")
+def generate(model, input_ids, images=None, attention_mask=None, generation_config=None, stopping_criteria=None, streamer=None,
+             use_graph=True, fp8_weights=False, seed=None, **kw):
+    """transformers' `GenerationMixin.generate` for the modes the reference reaches (module docstring).  `streamer` follows HF's
+    protocol (`put(prompt ids)`, `put(next tokens)` every step, `end()`): serve/cli.py:93-104 passes a TextStreamer.  Every
+    other HF option is either implemented, accepted at its neutral value, or refused by name - nothing is silently dropped."""
+    o = _resolve_options(generation_config, kw)
+    max_new_tokens, max_length, eos_token_id, pad_token_id = o["max_new_tokens"], o["max_length"], o["eos_token_id"], o["pad_token_id"]
+    do_sample, temperature, top_k, top_p = o["do_sample"], o["temperature"], o["top_k"], o["top_p"]
+    num_beams, length_penalty, early_stopping, use_cache = o["num_beams"], o["length_penalty"], o["early_stopping"], o["use_cache"]
     cfg = model.config
     eos_ids = _as_list(cfg.eos_token_id if eos_token_id is None else eos_token_id)
     pad = pad_token_id if pad_token_id is not None else (cfg.pad_token_id if cfg.pad_token_id is not None else (eos_ids[0] if eos_ids else 0))
@@ -87,13 +127,21 @@ def generate(model, input_ids, images=None, attention_mask=None, max_new_tokens=
     if num_beams > 1:
         if do_sample:
             raise NotImplementedError("beam-sample is not one of the reference's decoding modes (eval scripts: num_beams=5, do_sample unset)")
+        if streamer is not None:  # (transformers raises the same way)
+            raise ValueError("`streamer` cannot be used with beam search. Make sure that `num_beams` is set to 1.")
         if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
             raise NotImplementedError("beam search takes un-padded prompts (the reference's eval scripts decode one prompt at a time)")
         return _beam_search(model, input_ids, images, num_beams, max_len, eos_ids, pad, length_penalty, early_stopping, stop, fp8_weights)
     sel = dict(do_sample=bool(do_sample), temperature=float(temperature), top_k=int(top_k or 0), top_p=float(top_p), seed=seed)
+    if streamer is not None:
+        streamer.put(input_ids.cpu())
     if not use_cache:
-        return _sample_recompute(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel)
-    return _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, use_graph, fp8_weights)
+        out = _sample_recompute(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, streamer)
+    else:
+        out = _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, use_graph, fp8_weights, streamer)
+    if streamer is not None:
+        streamer.end()
+    return out
 
 
 def _select(logits, V, sel, step):
@@ -101,7 +149,7 @@ def _select(logits, V, sel, step):
                            seed=sel["seed"], step=step)
 
 
-def _sample_recompute(model, ids, images, attention_mask, max_len, eos_ids, pad, stop, sel):
+def _sample_recompute(model, ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, streamer=None):
     """use_cache=False: full-sequence forward per token (the cross-check of the cached path)."""
     V = model.config.vocab_size
     unfinished = torch.ones(ids.shape[0], dtype=torch.bool, device=ids.device)
@@ -112,6 +160,8 @@ def _sample_recompute(model, ids, images, attention_mask, max_len, eos_ids, pad,
         nxt = _select(logits, V, sel, step).to(ids.device)
         if eos_ids:
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+        if streamer is not None:
+            streamer.put(nxt.cpu())
         ids = torch.cat([ids, nxt[:, None]], dim=1)
         if attention_mask is not None:
             attention_mask = torch.cat([attention_mask, torch.ones_like(attention_mask[:, :1])], dim=1)
@@ -121,7 +171,7 @@ def _sample_recompute(model, ids, images, attention_mask, max_len, eos_ids, pad,
             return ids
 
 
-def _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, use_graph, fp8_weights):
+def _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, pad, stop, sel, use_graph, fp8_weights, streamer=None):
     eng = model.engine
     B, P = input_ids.shape
     V = model.config.vocab_size
@@ -141,6 +191,8 @@ def _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, p
         if eos_ids:
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
         new.append(nxt)
+        if streamer is not None:
+            streamer.put(nxt.cpu())
         cur = torch.cat([ids, torch.stack(new, dim=1)], dim=1)  # (right-padded prompts: criteria see the pads in the middle)
         unfinished = unfinished & ~stop(cur, None)
         if not bool(unfinished.any()) or step + 1 == max_new:

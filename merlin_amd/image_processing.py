@@ -83,18 +83,28 @@ class CLIPImageProcessor:
     __call__ = preprocess
 
 
+def _short_edge_keeping_aspect(size_wh, image_size):
+    """'keep' mode: the short edge is image_size unless that would push the long edge past 2 x image_size.  The quotient is
+    formed as (2 n) / (long / short) like mm_utils.py:31-34 so that the int() truncation lands on the same pixel count."""
+    long_side, short_side = max(size_wh), min(size_wh)
+    return int(min((2 * image_size) / (long_side / short_side), image_size))
+
+
+def _plan(image, processor, image_size, mode):
+    """mode -> (image handed to the CLIP processor, processor overrides); unknown modes fall through to the processor's own
+    resize + centre crop (mm_utils.py:43-44)."""
+    no_crop = dict(do_center_crop=False)
+    if mode == "resize":   # squash to a square, nothing left for the processor to resample
+        return image.resize((image_size, image_size)), dict(no_crop, do_resize=False)
+    if mode == "pad":      # letterbox with the processor's mean colour, then resize the square
+        fill = tuple(int(c * 255) for c in processor.image_mean)
+        return expand2square(image, fill), dict(no_crop, size={"shortest_edge": image_size})
+    if mode == "keep":     # aspect ratio kept, long edge bounded
+        return image, dict(no_crop, size={"shortest_edge": _short_edge_keeping_aspect(image.size, image_size)})
+    return image, {}
+
+
 def process_image(image, processor, image_size, mode="resize"):
-    """`BaseDataset.image_processor` (base_dataset.py:178-197): PIL image -> float32 [3, H, W]."""
-    if mode == "keep":
-        max_hw, min_hw = max(image.size), min(image.size)
-        aspect_ratio = max_hw / min_hw
-        max_len, min_len = image_size * 2, image_size
-        shortest_edge = int(min(max_len / aspect_ratio, min_len))
-        return processor.preprocess(image, return_tensors="pt", do_center_crop=False, size={"shortest_edge": shortest_edge})["pixel_values"][0]
-    if mode == "pad":
-        image = expand2square(image, tuple(int(x * 255) for x in processor.image_mean))
-        return processor.preprocess(image, return_tensors="pt", do_center_crop=False, size={"shortest_edge": image_size})["pixel_values"][0]
-    if mode == "resize":
-        image = image.resize((image_size, image_size))
-        return processor.preprocess(image, return_tensors="pt", do_resize=False, do_center_crop=False)["pixel_values"][0]
-    return processor.preprocess(image, return_tensors="pt")["pixel_values"][0]
+    """`BaseDataset.image_processor` (base_dataset.py:178-197 -> mm_utils.py:29-45): PIL image -> float32 [3, H, W]."""
+    image, overrides = _plan(image, processor, image_size, mode)
+    return processor.preprocess(image, return_tensors="pt", **overrides)["pixel_values"][0]

@@ -86,3 +86,18 @@ class MMGPTConfig(_Cfg):
         d["architectures"] = ["MMGPTLlamaForCausalLM"]
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(d, f, indent=2, default=str)
+
+
+def head_dim_of(config) -> int:
+    """transformers < 4.45 (the reference pins 4.31.0) has no `LlamaConfig.head_dim`, later versions may carry None."""
+    return int(getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads)
+
+
+def rope_theta_of(config) -> float:
+    t = getattr(config, "rope_theta", None)
+    if t is None:  # transformers >= 5: rope_parameters = {"rope_theta": ..., "rope_type": "default"}
+        rp = getattr(config, "rope_parameters", None) or {}
+        if rp.get("rope_type", "default") != "default":
+            raise NotImplementedError("only the default rotary embedding is on the reference's Llama path")
+        t = rp.get("rope_theta", 10000.0)
+    return float(t)

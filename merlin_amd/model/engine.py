@@ -26,6 +26,7 @@ import torch
 
 from .. import ops as O
 from .arena import Arena
+from .config import head_dim_of, rope_theta_of
 
 VT = "model.vision_tower.vision_tower.vision_model."
 
@@ -56,6 +57,7 @@ class HipEngine:
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
+        self._pver = None        # torch version counters of the parameters at the last forward (ensure_arena)
 
     # ------------------------------------------------------------------------------------------
     # parameter arena
@@ -105,7 +107,19 @@ class HipEngine:
             self._bind = None
         if self.arena.ensure_packed() or self._bind is None:
             self._bind_views()
+        # Parameters are views of the arena, so ANY in-place update of one (a stock torch.optim step on param.grad under HF
+        # Trainer, p.mul_(), clip-by-value, EMA swaps ...) changes the arena behind the derived copies.  torch counts in-place
+        # writes per tensor (`_version`): a changed signature drops the copies exactly like FusedAdamW.step / load_state_dict do.
+        # (Writes through `p.data` get a fresh version counter from torch and stay invisible: call weights_changed() after those.)
+        pv = self._param_versions()
+        if pv != self._pver:
+            if self._pver is not None:
+                self.weights_changed()
+            self._pver = pv
         return self.arena
+
+    def _param_versions(self):
+        return tuple(p._version for p in self.arena.params.values())
 
     def _bind_views(self):
         """Fused weight views (q|k|v, gate|up) over the arena."""
@@ -170,9 +184,7 @@ class HipEngine:
         if self.rope is None or self.rope.shape[0] < S or self.rope.device != device:
             # computed on the host exactly like transformers' LlamaRotaryEmbedding (fp32), then uploaded:
             # init-time plumbing; mh_rope_table is the device-side equivalent (tests compare them)
-            from .llama_mmgpt import rope_theta_of
-
-            D = cfg.head_dim
+            D = head_dim_of(cfg)
             n = max(S, 64)
             inv = 1.0 / (rope_theta_of(cfg) ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
             fr = torch.outer(torch.arange(n, dtype=torch.float32), inv)
@@ -403,7 +415,7 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     def _llama_layer_fwd(self, W, x, B, S, lens, keep, kv_out=None):
         cfg = self.model.config
-        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         h1 = O.rmsnorm_fwd(x, W.ln1, eps)
         qkv = O.gemm_nt_rope(h1, W.wqkv, self.rope, S, H, D)  # q|k|v projection with RoPE in the GEMM epilogue
@@ -431,7 +443,7 @@ class HipEngine:
         each GEMM (dynamic scaling), weights per output channel (once); residual stream, norms, RoPE, attention and
         SwiGLU stay 16-bit.  Forward only."""
         cfg = self.model.config
-        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         _, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)
         qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
@@ -464,7 +476,7 @@ class HipEngine:
 
     def _llama_layer_fwd_fp8_train(self, W, li, x, B, S, lens, keep):
         cfg = self.model.config
-        d, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        d, H, D = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         Q = self.fp8_train_weights(li)
         h1, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)  # norm + row quantisation of its output in one launch
@@ -492,7 +504,7 @@ class HipEngine:
     def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
         A = self.arena
-        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         if saved is None:
             _, saved = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=True)
@@ -535,7 +547,7 @@ class HipEngine:
     def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):
         cfg = self.model.config
         A = self.arena
-        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+        d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         if saved is None:
             _, saved = self._llama_layer_fwd(W, x, B, S, lens, keep=True)
@@ -912,7 +924,7 @@ class HipEngine:
             return self._decode_step_fp8(tokens, cache)
         cfg = self.model.config
         A = self.arena
-        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
+        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg), cfg.vocab_size
         eps = cfg.rms_norm_eps
         emb = A.view("model.embed_tokens.weight", shape=(V, d))
         x = O.gather_rows(emb, tokens.to(A.flat.device).view(-1))
@@ -936,7 +948,7 @@ class HipEngine:
         cfg = self.model.config
         A = self.arena
         F8 = getattr(self, "_fp8", None) or self.quantize_decode_weights()
-        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
+        d, H, D, V = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg), cfg.vocab_size
         eps = cfg.rms_norm_eps
         emb = A.view("model.embed_tokens.weight", shape=(V, d))
         x = O.gather_rows(emb, tokens.to(A.flat.device).view(-1))

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import modules as M
 from .config import MMGPTConfig
+from .config import head_dim_of, rope_theta_of  # noqa: F401  (re-exported)
 from .engine import HipEngine
 from .vision import build_projector, build_vision_tower
 
@@ -55,16 +56,6 @@ def _check_config(config):
         raise NotImplementedError("LlamaMLP uses silu")
     if config.hidden_size % config.num_attention_heads:
         raise ValueError("hidden_size must be a multiple of num_attention_heads")
-
-
-def rope_theta_of(config) -> float:
-    t = getattr(config, "rope_theta", None)
-    if t is None:  # transformers >= 5: rope_parameters = {"rope_theta": ..., "rope_type": "default"}
-        rp = getattr(config, "rope_parameters", None) or {}
-        if rp.get("rope_type", "default") != "default":
-            raise NotImplementedError("only the default rotary embedding is on the reference's Llama path")
-        t = rp.get("rope_theta", 10000.0)
-    return float(t)
 
 
 class MMGPTLlamaModel(nn.Module):

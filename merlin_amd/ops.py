@@ -133,8 +133,9 @@ def gemv(x, w, out=None, resid=None, out_f32=False, n=None):
     assert w.shape[1] == K and x.dtype == w.dtype
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    for m0 in range(0, M, 16):
-        mm = min(16, M - m0)
+    step = _gemv_rows_per_launch(K)
+    for m0 in range(0, M, step):
+        mm = min(step, M - m0)
         xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
         rs = resid[m0:m0 + mm] if resid is not None else None
         L.check(L.lib().mh_gemv(p(xs), i64(_rowmajor(xs)), p(w), i64(_rowmajor(w)), p(os_), i64(_rowmajor(os_)), p(rs),
@@ -194,8 +195,9 @@ def gemv_fp8w(x, qw, out=None, resid=None, out_f32=False, n=None):
     assert q.shape[1] == K
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    for m0 in range(0, M, 16):
-        mm = min(16, M - m0)
+    step = _gemv_rows_per_launch(K)
+    for m0 in range(0, M, step):
+        mm = min(step, M - m0)
         xs, os_ = x[m0:m0 + mm], out[m0:m0 + mm]
         rs = resid[m0:m0 + mm] if resid is not None else None
         L.check(L.lib().mh_gemv_fp8w(p(xs), i64(_rowmajor(xs)), p(q), p(sc), p(os_), i64(_rowmajor(os_)), p(rs),
@@ -900,6 +902,13 @@ def gemv_mfma_min_rows(rows: int):
 def gemv_mfma_pair_min_rows(rows16: int, rows_fp8: int):
     """A/B switch: row counts from which the SwiGLU / RoPE-append projections use the MFMA form (<= 0: defaults 6 / 4)."""
     L.lib().mh_gemv_mfma_pair_min_rows(i32(rows16), i32(rows_fp8))
+
+
+def _gemv_rows_per_launch(K):
+    """Activation rows one mh_gemv / mh_gemv_fp8w launch takes: 16 through the MFMA form (needs K % 32 == 0 and the MFMA row
+    threshold within reach), 8 through the wave-per-row form otherwise (csrc/decode.hip gemv_impl returns MH_ERR_ARG for 9-16
+    rows there: e.g. beam search with 9-16 beam rows on a model whose K is a multiple of 8 but not of 32)."""
+    return 16 if (K % 32 == 0 and _gemv_mfma_min <= 9) else 8
 
 
 def _gemv_fused_rows_ok(M, K):

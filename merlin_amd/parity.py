@@ -13,6 +13,7 @@ import torch
 from . import _lib as L
 from . import ops as O
 from ._lib import f32, i32, i64, p
+from .model.config import head_dim_of
 from .ops import _stream
 
 VT = "model.vision_tower.vision_tower.vision_model."
@@ -101,7 +102,7 @@ def forward(engine, input_ids, attention_mask, labels, images):
     inner = m.get_model()
     tower = getattr(inner, "vision_tower", None)
     B, S = input_ids.shape
-    T, d, ff, H, D = B * S, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+    T, d, ff, H, D = B * S, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
     rope = engine._rope_table(S, dev)
     input_ids = input_ids.to(dev).contiguous()
     lens = am = None

@@ -28,6 +28,7 @@ class _FakeEngine:
         self.on_backward_begin = None
         self.buckets = buckets
         self.fresh = True
+        self.weight_version = 0  # HipEngine bumps it on every optimizer step / weight load
 
     def backward(self, value):
         """local gradient of this micro-step = `value` everywhere (written when fresh, accumulated otherwise)."""
@@ -144,6 +145,18 @@ def _accum_worker(rank, world, port, q):
             ok = False
         except RuntimeError as e:
             ok &= "no_sync" in str(e)
+        # after an optimizer step + zero_grad(set_to_none=False) the gradients are zero but still ATTACHED (the arena
+        # reports fresh = False); that is a valid new window, recognised by the weights having changed since the reduce ...
+        eng.weight_version += 1
+        for n in names:
+            A.gview(n).zero_()
+        eng.backward(float(rank + 1))
+        ok &= all(bool((A.gview(n) == float(sum(r + 1 for r in range(world)))).all()) for n in names)
+        # ... and without a step (skipped update) through GradSync.zero_grad()
+        sync.zero_grad(set_to_none=False)
+        A.gflat.zero_()  # (this CPU stand-in has no .grad views attached for zero_grad to reach)
+        eng.backward(2.0)
+        ok &= all(bool((A.gview(n) == 2.0 * world).all()) for n in names)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

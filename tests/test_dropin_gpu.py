@@ -307,3 +307,45 @@ def test_fp8_weight_copies_follow_the_weights():
     before = model.get_model().layers[0].mlp.up_proj.weight.detach().clone()
     opt.step()
     assert torch.equal(model.get_model().layers[0].mlp.up_proj.weight.detach(), before)
+
+
+@pytest.mark.parametrize("mode", ["bf16_tower", "fp8_train", "fp8_forward"])
+def test_stock_torch_optimizer_step_invalidates_derived_weight_copies(mode):
+    """parameters are arena views, so HF Trainer's torch.optim.AdamW or any in-place
+    parameter update changes the arena behind the cached derived copies (K-padded patch-embedding weight, fp8 weight copies).
+    The engine watches the parameters' torch version counters: the next forward must see the new values - compared with a
+    second model that received the SAME update through an explicit weights_changed()."""
+    from oracle import cases as C
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_1img")
+    b = _to_dev(batch)
+
+    def run(explicit):
+        model = _build(cfg, torch.bfloat16)
+        if mode == "fp8_train":
+            model.fp8_training = True
+        if mode == "fp8_forward":
+            model.fp8_forward = True
+            with torch.no_grad():
+                model(**b)
+            model.fp8_forward = False
+        model(**b).loss.backward()  # (also builds the derived copies of this mode)
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.5)
+        opt.step()
+        if explicit:
+            model.engine.weights_changed()
+        if mode == "fp8_forward":
+            model.fp8_forward = True
+        with torch.no_grad():
+            return model(**b).logits.float().clone(), model
+
+    l_auto, m = run(False)
+    l_ref, _ = run(True)
+    assert torch.equal(l_auto, l_ref), "the forward after a stock optimizer step still used stale derived weights"
+    # and a manual in-place edit of one tower weight is seen as well
+    pw = m.get_model().vision_tower.vision_tower.vision_model.embeddings.patch_embedding.weight
+    with torch.no_grad():
+        pw.mul_(1.5)
+        l2 = m(**b).logits.float()
+    assert float((l2 - l_auto).abs().max()) > 0

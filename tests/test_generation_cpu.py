@@ -63,3 +63,28 @@ def test_counter_uniform_is_reproducible_and_uniform():
     u = np.array([G.counter_uniform(123, s, r) for s in range(200) for r in range(5)])
     assert (u >= 0).all() and (u < 1).all() and abs(u.mean() - 0.5) < 0.03 and len(set(u.tolist())) > 990
     assert G.counter_uniform(123, 7, 2) == G.counter_uniform(123, 7, 2) != G.counter_uniform(124, 7, 2)
+
+
+def test_generate_options_are_implemented_neutral_or_refused_by_name():
+    """generate() must not swallow unknown keyword arguments (serve/cli.py passes streamer=..., HF callers pass
+    return_dict_in_generate / generation_config / logits_processor ...)."""
+    import pytest
+    from merlin_amd.generation import _resolve_options
+
+    o = _resolve_options(None, dict(do_sample=True, temperature=0.2, max_new_tokens=7, output_scores=False, return_dict_in_generate=False,
+                                    logits_processor=None, min_length=0, repetition_penalty=1.0))
+    assert o["do_sample"] is True and o["temperature"] == 0.2 and o["max_new_tokens"] == 7 and o["top_k"] == 50 and o["num_beams"] == 1
+    for bad in (dict(return_dict_in_generate=True), dict(output_scores=True), dict(repetition_penalty=1.2), dict(min_length=5),
+                dict(logits_processor=[object()]), dict(num_return_sequences=3)):
+        with pytest.raises(NotImplementedError):
+            _resolve_options(None, bad)
+    with pytest.raises(TypeError):
+        _resolve_options(None, dict(not_a_generate_option=1))
+
+    class GC:  # a transformers.GenerationConfig stand-in: fields first, explicit kwargs over them
+        num_beams, max_new_tokens, do_sample, temperature, repetition_penalty = 5, 12, False, None, 1.0
+    o = _resolve_options(GC(), dict(max_new_tokens=3))
+    assert o["num_beams"] == 5 and o["max_new_tokens"] == 3 and o["temperature"] == 1.0
+    GC.repetition_penalty = 1.3
+    with pytest.raises(NotImplementedError):
+        _resolve_options(GC(), {})

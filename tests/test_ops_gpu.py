@@ -500,6 +500,26 @@ def test_gemv_small_m(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(12, 264, 264), (16, 520, 72), (23, 128, 40)])
+def test_gemv_9_to_16_rows_without_the_mfma_form(ops, dtype, M, N, K):
+    """9-16 activation rows exist only in the MFMA form (K % 32 == 0, row threshold at its default); the wrappers
+    chunk by 8 rows when that form is out of reach (K a multiple of 8 only, or mh_gemv_mfma_min_rows(17)) instead of raising."""
+    x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    ref = x.float() @ w.float().t()
+    assert relerr(ops.gemv(x, w), ref) < 3 * EPS16[dtype]
+    qw = ops.quant_fp8_b128(w) if K % 128 == 0 else None
+    try:
+        ops.gemv_mfma_min_rows(17)
+        x2, w2 = rnd(M, 256, dtype=dtype), rnd(N, 256, dtype=dtype, seed=1, scale=0.5)
+        assert relerr(ops.gemv(x2, w2), x2.float() @ w2.float().t()) < 3 * EPS16[dtype]
+        q2 = ops.quant_fp8_b128(w2)
+        assert relerr(ops.gemv_fp8w(x2, q2), x2.float() @ w2.float().t()) < 0.08
+    finally:
+        ops.gemv_mfma_min_rows(0)
+    del qw
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,ff,K", [(1, 11008, 4096), (2, 520, 264), (3, 1000, 4096), (5, 11008, 4096), (8, 136, 2048), (11, 256, 512)])
 def test_gemv_swiglu_fused(ops, dtype, M, ff, K):
     """Decode-step gate|up projection + SwiGLU in one launch = the two launches (gate / up rounded to 16 bits before the activation;

@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself as N workers (one per GPU, rendezvous on
+127.0.0.1) and still prints ONE line; under torchrun it uses the environment it is given.  `--dry-run` swaps the model for a CPU
+stand-in over gloo (tests/test_bench_cpu.py: launcher, GradSync, timing protocol and the JSON line at world size 2, no GPU).
 
 A "step" = one full training step of the hot path on one synthetic interpair batch per GPU
 (BASELINE cfg 3/4: B=8 sequences x S=4096 = 6 x 336-px frames + trajectory text, ViT-L/14 + mlp
@@ -52,16 +55,54 @@ def algorithmic_flops_fwd(B, S, n_img, vit_layers_used=23):
     return llama + vit + proj
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Time the CPU oracle (oracle/ref_cpu.py, a port of the reference's CPU forward pinned to the
-    reference by golden vectors) on the host cores, on a bounded sample of the cfg-3 workload:
-    ONE sequence (S=4096, 6 frames): embed+splice, 2 of the 23 live ViT layers, 2 of the 32 decoder layers and
-    lm_head+CE are timed (fp32, all host threads) and scaled to full depth."""
+def _alias_layers(P, cfg, R):
+    """Timing only: layer i of both towers points at layer 0's tensors, so a FULL-DEPTH forward runs without drawing 7 B random
+    numbers on the host first (one decoder layer is 0.8 GB in fp32 - far larger than the host caches, so nothing is flattered)."""
+    out = dict(P)
+    for k in list(P):
+        for pre, n in (("model.layers.", cfg.num_hidden_layers), ("model.vision_tower.vision_tower.vision_model.encoder.layers.", cfg.v_num_hidden_layers)):
+            if k.startswith(pre + "0."):
+                for i in range(1, n):
+                    out[pre + f"{i}." + k[len(pre) + 2:]] = P[k]
+    return out
+
+
+def cpu_baseline(seconds_budget=100.0):
+    """The CPU oracle (oracle/ref_cpu.py = a port of the reference's CPU forward, pinned to the reference by golden vectors)
+    timed on this box's host cores, fp32, all torch threads (SURVEY §8d "CPU reference timing"):
+      * `value` = BASELINE cfg 1 at FULL depth (one 336-px image + 32-token caption, S = 613, 24-layer ViT-L with 23 live layers +
+        32-layer Llama-7B + lm_head + CE): 3 warm-up + 5 timed forwards, median - fewer when one forward is too slow for the budget;
+      * `s4096_extrapolated` = one cfg-3 sequence (S = 4096, 6 frames) with 2/23 ViT + 2/32 decoder layers timed and scaled to depth."""
+    import statistics
+
     from merlin_amd import synth
     from oracle import ref_cpu as R
 
     torch.manual_seed(0)
     nthreads = torch.get_num_threads()
+    # ---- cfg 1, full depth ----
+    one = R.OracleConfig(num_hidden_layers=1, v_num_hidden_layers=1)
+    full = R.OracleConfig()
+    P1 = {k: torch.empty(s).normal_(0, 0.02) if len(s) > 1 else torch.ones(s) for k, s in R.param_shapes(one).items()}
+    P = _alias_layers(P1, full, R)
+    b1 = synth.single_image_batch()
+    S1 = int(b1["input_ids"].shape[1])
+    times = []
+    t_begin = time.perf_counter()
+    with torch.no_grad():
+        def fwd():
+            t0 = time.perf_counter()
+            R.forward(P, full, b1["input_ids"], b1["attention_mask"], b1["labels"], b1["images"])
+            return time.perf_counter() - t0
+        first = fwd()
+        n_warm, n_timed = (3, 5) if first * 8 <= seconds_budget else ((1, 3) if first * 4 <= seconds_budget else (1, 1))
+        for _ in range(n_warm - 1):
+            fwd()
+        for _ in range(n_timed):
+            times.append(fwd())
+    med = statistics.median(times)
+    del P, P1
+    # ---- one cfg-3 sequence, bounded sample scaled to depth ----
     cfg = R.OracleConfig(num_hidden_layers=2, v_num_hidden_layers=3)  # select_layer=-2 -> 2 live ViT layers
     P = {k: torch.empty(s).normal_(0, 0.02) if len(s) > 1 else torch.ones(s) for k, s in R.param_shapes(cfg).items()}
     batch = synth.interpair_batch(B=1, S=4096)
@@ -80,13 +121,19 @@ def cpu_baseline(seconds_budget=30.0):
         logits = torch.nn.functional.linear(h, P["lm_head.weight"])
         R.shifted_ce(logits, batch["labels"])
         t_parts["head"] = time.perf_counter() - t0
-    full = t_parts["vit2+proj"] * 23 / 2 + t_parts["splice"] + t_parts["llama2"] * 32 / 2 + t_parts["head"]
-    return {"value": round(4096 / full, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
-            "sample": "1 interpair sequence (S=4096, 6 frames) fp32 forward: 2/23 ViT layers + 2/32 decoder layers + lm_head+CE timed, "
-                      f"scaled to full depth ({full:.1f} s/sequence est.; parts {json.dumps({k: round(v, 2) for k, v in t_parts.items()})})"}
+    est = t_parts["vit2+proj"] * 23 / 2 + t_parts["splice"] + t_parts["llama2"] * 32 / 2 + t_parts["head"]
+    return {"value": round(S1 / med, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "sample": f"BASELINE cfg 1 at full depth (1 x 336px image + 32-token caption, S={S1}; ViT-L 23 live layers + 32 decoder layers + "
+                      f"lm_head + CE), fp32 forward, {n_warm} warm-up + {n_timed} timed, median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f}; "
+                      "one layer's random weights aliased across the depth - timing only)",
+            "seconds_per_forward": round(med, 3), "warmup_forwards": n_warm, "timed_forwards": n_timed,
+            "s4096_extrapolated": {"value": round(4096 / est, 3), "unit": "tokens/s", "extrapolated": True,
+                                   "sample": "1 interpair sequence (S=4096, 6 frames): 2/23 ViT layers + 2/32 decoder layers + lm_head+CE timed, "
+                                             f"scaled to full depth ({est:.1f} s/sequence est.; parts {json.dumps({k: round(v, 2) for k, v in t_parts.items()})})"},
+            "wall_s": round(time.perf_counter() - t_begin, 1)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -102,10 +149,103 @@ def main():
                     "gradient checkpointing) instead of keeping activations resident in the 288 GB of HBM")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--no-forward-leg", action="store_true", help="skip the extra forward-only timing after the training steps")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg-2 (S=613) row of the N=1 line's `extras`")
     ap.add_argument("--fp8-forward", action="store_true", help="with --fwd-only: decoder Linears on the scaled-fp8 MFMA (e4m3 operands, "
                     "per-row scales); NOT the headline configuration (dtype field says so)")
-    args = ap.parse_args()
-    if os.environ.get("MH_GEMM_FORCE"):  # A/B arm selection for kernel development (see mh_gemm_force_kernel)
+    ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the model over gloo: exercises the launcher, GradSync, the "
+                    "barrier / max-over-ranks timing and the JSON line without a GPU (tests/test_bench_cpu.py); the numbers mean nothing")
+    ap.add_argument("--min-free-gb", type=float, default=10.0, help="N>1: if less HBM than this stays free next to RCCL's buffers after the "
+                    "first warm-up step, every rank switches to layer recompute (reported as `recompute_fallback`)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a torchrun environment: re-launch as N workers of ONE node (one process per GPU,
+    rendezvous on 127.0.0.1, RCCL over xGMI), the same command line the driver uses; rank 0 of the children prints the line."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+class _DryEngine:
+    """--dry-run: the bucket protocol of HipEngine.backward on CPU tensors (a few small matmuls as 'compute'), so that the REAL
+    GradSync, launcher, timing protocol and JSON assembly run at world size > 1 without a GPU."""
+
+    def __init__(self, rank):
+        from merlin_amd.model.arena import Arena
+
+        names = [f"model.layers.{i}.{n}" for i in range(4) for n in ("a.weight", "b.weight")] + ["lm_head.weight"]
+        self.arena = Arena([(n, torch.nn.Parameter(torch.zeros(64, 64))) for n in names])
+        self.arena.flat = torch.zeros(self.arena.total)
+        self.arena.gflat = torch.zeros(self.arena.total)
+        self.buckets = [["lm_head.weight"]] + [[n for n in names if f".{i}." in n] for i in reversed(range(4))]
+        self.on_grads_ready = self.on_backward_begin = None
+        self.weight_version = 0
+        self.save_activations = True
+        self.x = torch.randn(64, 64, generator=torch.Generator().manual_seed(rank))
+
+    def step(self, sync):
+        if self.on_backward_begin is not None:
+            self.on_backward_begin(True)
+        for names in self.buckets:
+            for n in names:
+                self.arena.gview(n).copy_(self.x @ self.x.t())
+            if self.on_grads_ready is not None:
+                self.on_grads_ready(names)
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(None)
+        self.arena.flat.add_(self.arena.gflat, alpha=-1e-3 * (sync.grad_scale if sync else 1.0))
+        self.weight_version += 1
+        return self.arena.gflat.sum()
+
+
+def kernel_source_stamp():
+    """sha256 over the HIP sources: profiles/*traffic*.json files carry it, and a PMC summary taken on other kernels is not quoted."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "merlin_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def read_traffic(args):
+    """HBM/fabric traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+    (tools/pmc_step_traffic.sh; PMC collection cannot run inside the timed process).  The committed summary is quoted only when
+    it was taken on the kernel sources of THIS build (stamp) and for the default configuration."""
+    if args.config != "cfg3" or args.fwd_only or args.fp8_train or args.recompute or args.dry_run:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except Exception:
+        return None, "no PMC summary for this round (profiles/r03_gemm_traffic.json)"
+    if t.get("kernel_source_stamp") != kernel_source_stamp():
+        return None, f"profiles/r03_gemm_traffic.json was taken on other kernel sources (stamp {t.get('kernel_source_stamp')}): not quoted"
+    return round(t["traffic_bytes_per_launch"] / 1e9, 3), "GB per launch (L2<->fabric incl. Infinity-Cache hits, PMC: profiles/r03_gemm_traffic.json; " \
+        f"algorithmic {t.get('algorithmic_bytes_per_launch', 0) / 1e9:.3f} GB per launch)"
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)
+    if os.environ.get("MH_GEMM_FORCE") and not args.dry_run:  # A/B arm selection for kernel development (see mh_gemm_force_kernel)
         from merlin_amd import ops as _O
         _O.gemm_force_kernel(int(os.environ["MH_GEMM_FORCE"]))
 
@@ -113,162 +253,231 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+        dev_sync = lambda: None  # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dev_sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from merlin_amd import ops as O
+    def all_max(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    def all_min(x):
+        return -all_max(-float(x))
+
+    def all_sum_int(x):
+        if world == 1:
+            return int(x)
+        t = torch.tensor([int(x)], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t)
+
     from merlin_amd import synth
     from merlin_amd.dp import GradSync
-    from merlin_amd.model.llama_mmgpt import build_synthetic_model
-    from merlin_amd.optim import FusedAdamW
 
-    assert O.arch_ok(local_rank), "bench.py needs a gfx950 (MI355X) device"
-    model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
-    model.engine.save_activations = not args.recompute
-    if args.fp8_forward:
-        assert args.fwd_only, "--fp8-forward is forward-only"
-        model.fp8_forward = True
-    if args.config == "cfg3":
-        B = args.batch or 8
-        batch = synth.interpair_batch(B=B, S=4096, rank=rank)
-        workload = f"interpair: B={B}/GPU x S=4096 (6 x 336px frames + trajectory text), ViT-L/14-336 + mlp projector + Llama-7B"
-    elif args.config == "cfg3-ragged":
-        B = args.batch or 8
-        batch = synth.interpair_batch(B=B, S=4096, rank=rank, ragged=True)
-        workload = f"interpair ragged: B={B}/GPU, lengths <= 4096 right-padded (key-padding branch), 6 frames, ViT-L/14-336 + mlp + Llama-7B"
-    elif args.config in ("cfg5", "cfg5-bf16"):
-        B = args.batch or 4
-        batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
-        if args.config == "cfg5":
-            args.fp8_train = True
-            workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers"
-        else:
-            workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
+    O = None
+    model = None
+    recompute_fallback = False
+    if dry:
+        eng = _DryEngine(rank)
+        B, S, n_img, n_tok = 2, 64, 0, 128
+        workload = "DRY RUN: CPU stand-in over gloo (launcher / GradSync / timing protocol only)"
+        sync = GradSync(eng) if world > 1 else None
+
+        def step():
+            return eng.step(sync)
     else:
-        B = 1
-        batch = synth.single_image_batch()
-        workload = "single 336px image + 32-token caption (S=613), ViT-L/14-336 + mlp projector + Llama-7B"
-    if args.fp8_train:
-        model.fp8_training = True
-    S = batch["input_ids"].shape[1]
-    n_img = sum(int(im.shape[0]) for im in batch["images"])
-    dbatch = dict(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
-                  labels=batch["labels"].to(dev), images=[im.to(dev) for im in batch["images"]])
-    # the reference's recipe (pretrain.sh:23-29): --llrd, lr 5e-5, beta2 0.95, wd 0.05, cosine warm-up; HF's default
-    # max_grad_norm=1.0 clipping - all of it inside the timed step
-    from merlin_amd.optim import vit_lr_scale, cosine_with_warmup
-    opt = FusedAdamW(model.engine, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
-    it = [0]
-    sync = GradSync(model.engine) if world > 1 else None
+        from merlin_amd import ops as O
+        from merlin_amd.model.llama_mmgpt import build_synthetic_model
+        from merlin_amd.optim import FusedAdamW, cosine_with_warmup, vit_lr_scale
 
-    def step():
-        if args.fwd_only:
-            with torch.no_grad():
-                return model(**dbatch).loss
-        out = model(**dbatch)
-        out.loss.backward()
-        # (GradSync joins the communication stream at the end of backward: the clip sees the all-reduced gradients)
-        opt.step(grad_scale=(sync.grad_scale if sync else 1.0), max_grad_norm=1.0, lr_mult=cosine_with_warmup(it[0] + 10, 1000, 0.01))
-        it[0] += 1
-        opt.zero_grad()
-        return out.loss
+        assert O.arch_ok(local_rank), "bench.py needs a gfx950 (MI355X) device"
+        model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
+        eng = model.engine
+        eng.save_activations = not args.recompute
+        if args.fp8_forward:
+            assert args.fwd_only, "--fp8-forward is forward-only"
+            model.fp8_forward = True
+        if args.config == "cfg3":
+            B = args.batch or 8
+            batch = synth.interpair_batch(B=B, S=4096, rank=rank)
+            workload = f"interpair: B={B}/GPU x S=4096 (6 x 336px frames + trajectory text), ViT-L/14-336 + mlp projector + Llama-7B"
+        elif args.config == "cfg3-ragged":
+            B = args.batch or 8
+            batch = synth.interpair_batch(B=B, S=4096, rank=rank, ragged=True)
+            workload = f"interpair ragged: B={B}/GPU, lengths <= 4096 right-padded (key-padding branch), 6 frames, ViT-L/14-336 + mlp + Llama-7B"
+        elif args.config in ("cfg5", "cfg5-bf16"):
+            B = args.batch or 4
+            batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
+            if args.config == "cfg5":
+                args.fp8_train = True
+                workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers"
+            else:
+                workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
+        else:
+            B = 1
+            batch = synth.single_image_batch()
+            workload = "single 336px image + 32-token caption (S=613), ViT-L/14-336 + mlp projector + Llama-7B"
+        if args.fp8_train:
+            model.fp8_training = True
+        S = batch["input_ids"].shape[1]
+        n_img = sum(int(im.shape[0]) for im in batch["images"])
+        n_tok = int(batch["attention_mask"].sum())  # the metric counts sequence positions, padding excluded
+
+        def to_dev(b):
+            return dict(input_ids=b["input_ids"].to(dev), attention_mask=b["attention_mask"].to(dev), labels=b["labels"].to(dev),
+                        images=[im.to(dev) for im in b["images"]])
+
+        dbatch = to_dev(batch)
+        # the reference's recipe (pretrain.sh:23-29): --llrd, lr 5e-5, beta2 0.95, wd 0.05, cosine warm-up; HF's default
+        # max_grad_norm=1.0 clipping - all of it inside the timed step
+        opt = FusedAdamW(eng, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
+        it = [0]
+        sync = GradSync(eng) if world > 1 else None
+
+        def train_step(db):
+            out = model(**db)
+            out.loss.backward()
+            # (GradSync joins the communication stream at the end of backward: the clip sees the all-reduced gradients)
+            opt.step(grad_scale=(sync.grad_scale if sync else 1.0), max_grad_norm=1.0, lr_mult=cosine_with_warmup(it[0] + 10, 1000, 0.01))
+            it[0] += 1
+            opt.zero_grad()
+            return out.loss
+
+        def step():
+            if args.fwd_only:
+                with torch.no_grad():
+                    return model(**dbatch).loss
+            return train_step(dbatch)
 
     for wi in range(args.warmup):
         tw = time.perf_counter()
         loss = step()
         if os.environ.get("MH_BENCH_PER_STEP"):  # warm-up profile (stderr): how many steps until the step time is flat
-            torch.cuda.synchronize()
+            dev_sync()
             print(f"[bench] warm-up step {wi}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
-    torch.cuda.synchronize()
+        if wi == 0 and world > 1 and not dry and not args.fwd_only and eng.save_activations:
+            # RCCL has allocated its channels / staging buffers by now (the first all-reduces ran): with activations resident the
+            # step peaks at ~251 of 288 GB on one GPU - if less than --min-free-gb stays free on ANY rank, all ranks recompute
+            dev_sync()
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            headroom = (free_b + torch.cuda.memory_reserved(dev) - torch.cuda.max_memory_allocated(dev)) / 1e9
+            if all_min(headroom) < args.min_free_gb:
+                eng.save_activations = False
+                recompute_fallback = True
+                torch.cuda.empty_cache()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    O.profile_start()
+    dev_sync()
+    if O is not None:
+        O.profile_start()
+    if sync is not None:
+        sync.pop_timing()
+        sync.timing = True
+    if not dry:
+        torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     dt = time.perf_counter() - t0
-    prof = O.profile_stop()
+    prof = O.profile_stop() if O is not None else {}
+    prof_bytes = dict(O.LAST_PROFILE_BYTES) if O is not None else {}
+    comm = None
+    if sync is not None:
+        comm = sync.pop_timing()
+        sync.timing = False
     loss_val = float(loss.detach())
+    peak_gb = 0.0 if dry else torch.cuda.max_memory_allocated(dev) / 1e9
     # ---- forward-only leg (same batch, same weights; not part of `value`) ----
     fwd_ms = None
-    if not args.fwd_only and not args.no_forward_leg:
+    if not dry and not args.fwd_only and not args.no_forward_leg:
         nf = max(3, min(10, args.steps))
         with torch.no_grad():
             for _ in range(2):
                 model(**dbatch)
-            torch.cuda.synchronize()
+            dev_sync()
             if world > 1:
                 dist.barrier()
             tf0 = time.perf_counter()
             for _ in range(nf):
                 model(**dbatch)
-            torch.cuda.synchronize()
+            dev_sync()
             if world > 1:
                 dist.barrier()
             fwd_dt = time.perf_counter() - tf0
-        if world > 1:
-            t = torch.tensor([fwd_dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fwd_dt = float(t)
-        fwd_ms = fwd_dt / nf * 1e3
-    n_tok = int(batch["attention_mask"].sum())  # the metric counts sequence positions, padding excluded
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-        c = torch.tensor([n_tok], device=dev, dtype=torch.int64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_tok_all = int(c)
-    else:
-        n_tok_all = n_tok
+        fwd_ms = all_max(fwd_dt) / nf * 1e3
+    dt = all_max(dt)
+    n_tok_all = all_sum_int(n_tok)
+    per_rank = None
+    if world > 1:  # per-rank peak HBM and communication times, gathered on rank 0
+        mine = torch.tensor([peak_gb, comm["comm_ms_total"] / args.steps, comm["comm_ms_exposed"] / args.steps], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(v), 2) for v in t] for t in allr]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
-    tokens = n_tok_all
-    value = tokens / (dt / args.steps)
-    fwd = algorithmic_flops_fwd(B, S, n_img)
+    value = n_tok_all / (dt / args.steps)
+    fwd = algorithmic_flops_fwd(B, S, n_img) if not dry else 0.0
     useful = fwd * (1.0 if args.fwd_only else 3.0)
     fp8_dom = "gemm_fp8" in prof and prof["gemm_fp8"][2] > prof.get("gemm_nt", (0, 0.0, 0.0))[2]
     n, work, gms = prof.get("gemm_fp8" if fp8_dom else "gemm_nt", (0, 0.0, 1e-9))
     ach = work / (gms * 1e-3) / 1e12
     peak = PEAK_FP8_TFLOPS if fp8_dom else PEAK_BF16_TFLOPS
-    # HBM/fabric traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass of this same command
-    # (PMC collection cannot run inside the timed process); the committed summary is read back here.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")) as f:
-            traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e9, 3) if args.config == "cfg3" and not args.fwd_only and not args.fp8_train else None
-    except Exception:
-        traffic = None
+    traffic, traffic_unit = read_traffic(args)
+    step_desc = "fwd only" if args.fwd_only else "fwd+bwd" + (" (layer recompute)" if not eng.save_activations else " (activations resident)") + "+allreduce+adamw"
     line = {
         "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
-                                                                                          "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else "bf16"),
+        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("cpu-fp32 (dry run)" if dry else "fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
+                  "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
-                   "step": "fwd only" if args.fwd_only else "fwd+bwd" + (" (layer recompute)" if args.recompute else " (activations resident)") + "+allreduce+adamw",
-                   "loss": round(loss_val, 4)},
+                   "step": step_desc, "loss": round(loss_val, 4)},
         "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
-        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+        "peak_hbm_gb": round(peak_gb, 1),
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "gemm_nt_256/gemm_nt_128 (bf16 MFMA GEMM, all launches)"),
+        "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "bf16 MFMA GEMM kernels (gemm_nt_256 / gemm_w4 / gemm_nt_128, all launches)"),
                      "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2<->fabric, PMC: profiles/r02_gemm_traffic.json)", "launches": n,
-                     "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3)},
+                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": traffic_unit, "launches": n,
+                     "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3),
+                     "algorithmic_gb_per_launch": round(prof_bytes.get("gemm_fp8" if fp8_dom else "gemm_nt", 0.0) / max(n, 1) / 1e9, 4)},
     }
-    if not fp8_dom:
+    if traffic and line["roofline"]["algorithmic_gb_per_launch"]:
+        line["roofline"]["traffic_over_algorithmic"] = round(traffic / line["roofline"]["algorithmic_gb_per_launch"], 2)
+    if dry:
+        line["dry_run"] = True
+    if world > 1:
+        line["rccl_ranks"] = world
+        line["comm_ms_total"] = round(max(r[1] for r in per_rank), 2)      # per step, slowest rank
+        line["comm_ms_exposed"] = round(max(r[2] for r in per_rank), 2)    # per step: compute stream idle at the end of backward
+        line["comm_collectives_per_step"] = comm["collectives"] // max(1, args.steps)
+        line["comm_gb_per_step"] = round(comm["bytes"] / max(1, args.steps) / 1e9, 3)
+        line["per_rank"] = [{"rank": i, "peak_hbm_gb": r[0], "comm_ms_total": r[1], "comm_ms_exposed": r[2]} for i, r in enumerate(per_rank)]
+        line["recompute_fallback"] = recompute_fallback
+    if not fp8_dom and not dry:
         sustained = sustained_mfma_tflops()
         if sustained:
             line["roofline"]["sustained_mfma_probe"] = {"tflops": round(sustained, 1), "frac_of_it": round(ach / sustained, 4),
@@ -278,7 +487,34 @@ def main():
         line["forward_only"] = {"ms_per_step": round(fwd_ms, 2), "tokens_per_s_per_gpu": round(n_tok / (fwd_ms * 1e-3), 1),
                                 "useful_tflops_per_gpu": round(fwd / (fwd_ms * 1e-3) / 1e12, 1),
                                 "mfma_roofline_frac": round(fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-    if not args.no_cpu_baseline and world == 1:  # (the reported CPU baseline belongs to the N = 1 line only)
+    if world == 1 and not dry and not args.no_extras and args.config == "cfg3" and not args.fwd_only and not args.fp8_train:
+        try:  # BASELINE cfg 2 (single image + caption, S = 613, B = 1) on the same model: a few training steps + forwards
+            b2 = synth.single_image_batch()
+            d2 = to_dev(b2)
+            S2 = int(b2["input_ids"].shape[1])
+            for _ in range(2):
+                train_step(d2)
+            dev_sync()
+            tq = time.perf_counter()
+            for _ in range(10):
+                train_step(d2)
+            dev_sync()
+            t_tr = (time.perf_counter() - tq) / 10
+            with torch.no_grad():
+                model(**d2)
+                dev_sync()
+                tq = time.perf_counter()
+                for _ in range(10):
+                    model(**d2)
+                dev_sync()
+                t_fw = (time.perf_counter() - tq) / 10
+            f2 = algorithmic_flops_fwd(1, S2, 1)
+            line["extras"] = {"cfg2": {"workload": "single 336px image + 32-token caption (S=613), B=1", "train_ms_per_step": round(t_tr * 1e3, 2),
+                                       "train_tokens_per_s": round(S2 / t_tr, 1), "forward_ms": round(t_fw * 1e3, 2),
+                                       "forward_tokens_per_s": round(S2 / t_fw, 1), "forward_mfma_roofline_frac": round(f2 / t_fw / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+        except Exception as e:
+            line["extras"] = {"cfg2": f"failed: {e}"}
+    if not args.no_cpu_baseline and world == 1 and not dry:  # (the reported CPU baseline belongs to the N = 1 line only)
         try:
             line["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # the baseline leg must never take the GPU number down

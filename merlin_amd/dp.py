@@ -22,6 +22,7 @@ all-reduced raises instead of silently counting the first micro-batch world^(k-1
 from __future__ import annotations
 
 import contextlib
+import time
 
 import torch
 import torch.distributed as dist
@@ -42,6 +43,8 @@ class GradSync:
         self._sync = True
         self._reduced = False  # the gradient arena holds all-reduced sums (until the next fresh backward / optimizer step)
         self._reduced_at = None  # engine.weight_version when they were reduced
+        self.timing = False      # bench.py: time every collective (events on the communication stream) and the exposed wait
+        self._t_coll, self._t_wait, self._t_host = [], [], [0.0, 0.0]
         engine.on_grads_ready = self._on_ready
         engine.on_backward_begin = self._on_begin
 
@@ -108,17 +111,48 @@ class GradSync:
             ev.record(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm_stream)
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self.timing:
+                    w.wait()  # (orders the communication stream - the current one here - behind the collective; no host wait)
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(self.comm_stream)
+                    self._t_coll.append((t0, t1))
             self.pending.append(w)
         else:
+            t0 = time.perf_counter()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.timing:
+                dt = (time.perf_counter() - t0) * 1e3
+                self._t_host[0] += dt
+                self._t_host[1] += dt  # synchronous on the host path: all of it is exposed
         self.n_collectives += 1
         self.bytes += buf.numel() * buf.element_size()
 
     def finish(self):
+        timed = self.timing and self.pending and self.comm_stream is not None
+        if timed:
+            a = torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream())
         for w in self.pending:
             w.wait()  # makes the current (compute) stream wait for the collective
+        if timed:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream())
+            self._t_wait.append((a, b))  # how long the compute stream stood still for the tail of the communication
         self.pending = []
+
+    def pop_timing(self):
+        """Call after a device synchronize: {comm_ms_total (sum over collectives, on the communication stream), comm_ms_exposed
+        (time the compute stream waited at the end of backward), collectives, bytes} since the last call."""
+        total = self._t_host[0] + sum(a.elapsed_time(b) for a, b in self._t_coll)
+        exposed = self._t_host[1] + sum(a.elapsed_time(b) for a, b in self._t_wait)
+        out = dict(comm_ms_total=total, comm_ms_exposed=exposed, collectives=self.n_collectives, bytes=self.bytes)
+        self._t_coll, self._t_wait, self._t_host = [], [], [0.0, 0.0]
+        self.n_collectives = self.bytes = 0
+        return out
 
     @property
     def grad_scale(self):

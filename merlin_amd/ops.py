@@ -40,23 +40,28 @@ def profile_start():
     _PROF = []
 
 
+LAST_PROFILE_BYTES = {}  # {kernel: algorithmic bytes (every operand and the result moved once)} of the last profile_stop()
+
+
 def profile_stop():
     """-> {kernel: (launches, total_work, total_ms)}; work = FLOPs (gemm/attn) or bytes."""
-    global _PROF
+    global _PROF, LAST_PROFILE_BYTES
     rec, _PROF = _PROF, None
     torch.cuda.synchronize()
-    out = {}
-    for name, work, s, e in rec or []:
+    out, nb = {}, {}
+    for name, work, s, e, b in rec or []:
         n, w, ms = out.get(name, (0, 0.0, 0.0))
         out[name] = (n + 1, w + work, ms + s.elapsed_time(e))
+        nb[name] = nb.get(name, 0.0) + b
+    LAST_PROFILE_BYTES = nb
     return out
 
 
 class _timed:
-    __slots__ = ("name", "work", "s")
+    __slots__ = ("name", "work", "s", "nbytes")
 
-    def __init__(self, name, work):
-        self.name, self.work = name, work
+    def __init__(self, name, work, nbytes=0.0):
+        self.name, self.work, self.nbytes = name, work, nbytes
 
     def __enter__(self):
         if _PROF is not None:
@@ -67,7 +72,7 @@ class _timed:
         if _PROF is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            _PROF.append((self.name, self.work, self.s, e))
+            _PROF.append((self.name, self.work, self.s, e, self.nbytes))
 
 
 def round_up(x: int, m: int) -> int:
@@ -120,7 +125,7 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
         epi |= EPI_OUT_F32
     else:
         assert out.dtype == a.dtype
-    with _timed("gemm_nt", 2.0 * M * N * K):
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + float(out.element_size()) * M * N):
         L.check(L.lib().mh_gemm(p(a), i64(lda), i32(int(a_t)), p(b), i64(ldb), i32(int(b_t)), p(out), i64(ldc), p(bias), p(resid),
                                 i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm")
     return out
@@ -332,7 +337,7 @@ def wgrad_tn(dy, x, out, accum):
     T, M = dy.shape
     T2, N = x.shape
     assert T == T2 and dy.dtype == x.dtype and M % 8 == 0 and N % 8 == 0
-    with _timed("gemm_nt", 2.0 * M * N * T):
+    with _timed("gemm_nt", 2.0 * M * N * T, 2.0 * (M * T + N * T + M * N)):
         plan = _tail_plan(M, N, T)
         if plan is None:
             _wgrad_call(dy, x, out, accum, int(L.lib().mh_gemm_splitk_max(i32(M), i32(N), i32(T))))
@@ -353,7 +358,7 @@ def gemm_nt_rope(a, b, table, S, H, D, out=None):
     N = b.shape[0]
     assert N == 3 * H * D and b.shape[1] == K and a.dtype == b.dtype
     out = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
-    with _timed("gemm_nt", 2.0 * M * N * K):
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         L.check(L.lib().mh_gemm_nt_rope(p(a), i64(_rowmajor(a)), p(b), i64(_rowmajor(b)), p(out), i64(_rowmajor(out)), i32(M), i32(N),
                                         i32(K), i32(dt_of(a)), p(table), i32(S), i32(D), i32(2 * H * D), _stream()), "mh_gemm_nt_rope")
     return out
@@ -365,7 +370,7 @@ def gemm_swiglu_fwd(x, wgu):
     ff = wgu.shape[0] // 2
     gu = torch.empty(M, 2 * ff, dtype=x.dtype, device=x.device)
     act = torch.empty(M, ff, dtype=x.dtype, device=x.device)
-    with _timed("gemm_nt", 2.0 * M * 2 * ff * K):
+    with _timed("gemm_nt", 2.0 * M * 2 * ff * K, 2.0 * (M * K + 2 * ff * K + 3 * M * ff)):
         L.check(L.lib().mh_gemm_swiglu_fwd(p(x), i64(_rowmajor(x)), p(wgu), i64(_rowmajor(wgu)), p(gu), i64(2 * ff), p(act), i64(ff),
                                            i32(M), i32(ff), i32(K), i32(dt_of(x)), _stream()), "mh_gemm_swiglu_fwd")
     return gu, act
@@ -378,7 +383,7 @@ def gemm_swiglu_bwd(dy, wd, gu):
     ff = wd.shape[1]
     assert wd.shape[0] == K and gu.shape == (M, 2 * ff)
     dgu = torch.empty_like(gu)
-    with _timed("gemm_nt", 2.0 * M * ff * K):
+    with _timed("gemm_nt", 2.0 * M * ff * K, 2.0 * (M * K + ff * K + 4 * M * ff)):
         L.check(L.lib().mh_gemm_swiglu_bwd(p(dy), i64(_rowmajor(dy)), p(wd), i64(_rowmajor(wd)), p(gu), i64(_rowmajor(gu)), p(dgu),
                                            i64(_rowmajor(dgu)), i32(M), i32(ff), i32(K), i32(dt_of(dy)), _stream()), "mh_gemm_swiglu_bwd")
     return dgu

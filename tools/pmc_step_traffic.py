@@ -1,5 +1,7 @@
 """Reduce the rocprofv3 --pmc passes of tools/pmc_step_traffic.sh to per-launch L2<->fabric traffic of the GEMM kernels."""
-import glob, json, sqlite3, sys, collections
+import glob, json, os, sqlite3, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d):
@@ -11,7 +13,7 @@ def load(d):
         ix = {k: i for i, k in enumerate(cols)}
         name_col = "kernel_name" if "kernel_name" in ix else "name"
         for r in c.execute("select * from counters_collection"):
-            if "gemm_nt" not in str(r[ix[name_col]]):
+            if "gemm_nt" not in str(r[ix[name_col]]) and "gemm_w4" not in str(r[ix[name_col]]):
                 continue
             out[r[ix["counter_name"]]] += float(r[ix["value"]])
             n[r[ix["counter_name"]]] += 1
@@ -32,7 +34,25 @@ wr, wr64 = b.get("TCC_EA0_WRREQ_sum", 0.0), b.get("TCC_EA0_WRREQ_64B_sum", 0.0)
 write_bytes = 64 * wr64 + 32 * (wr - wr64)
 hit, miss = a.get("TCC_HIT_sum", 0.0), a.get("TCC_MISS_sum", 0.0)
 L = max(1, launches)
-print(json.dumps({"kernel": "gemm_nt_256 + gemm_nt_128 (all launches of one cfg-3 training step)", "launches": launches,
+import bench  # noqa: E402  (kernel_source_stamp, algorithmic byte model)
+
+
+def algorithmic_bytes_per_step():
+    """A + B + C moved once per GEMM of one cfg-3 training step (SURVEY §8d shapes): what bench.py's `algorithmic_gb_per_launch` sums."""
+    T, d, ff, V, L = 8 * 4096, 4096, 11008, 32064, 32
+    def g(M, N, K, csize=2):
+        return 2.0 * (M * K + N * K) + csize * M * N
+    fwd = g(T, 3 * d, d) + g(T, d, d) + 2.0 * (T * d + 2 * ff * d + 3 * T * ff) + g(T, d, ff)
+    dgrad = g(T, ff, d) + 2.0 * 3 * T * ff + g(T, d, 2 * ff) + g(T, d, d) + g(T, d, 3 * d)
+    wgrad = g(d, ff, T) + g(2 * ff, d, T) + g(d, d, T) + g(3 * d, d, T)
+    head = g(T, V, d, 4) + g(T, d, V) + g(V, d, T)
+    Tv, vd, vff = 48 * 577, 1024, 4096
+    vit = 23 * (g(Tv, 3 * vd, vd) + g(Tv, vd, vd) + g(Tv, vff, vd) + g(Tv, vd, vff)) * 3 + g(Tv, vd, 640) * 2 + g(Tv, d, vd) * 3
+    return L * (fwd + dgrad + wgrad) + head + vit
+
+
+print(json.dumps({"kernel": "bf16 MFMA GEMM kernels (all launches of one cfg-3 training step)", "launches": launches,
+                  "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": algorithmic_bytes_per_step() / L,
                   "fabric_read_bytes_per_launch": read_bytes / L, "fabric_write_bytes_per_launch": write_bytes / L,
                   "traffic_bytes_per_launch": (read_bytes + write_bytes) / L, "l2_hit_rate": hit / max(1.0, hit + miss),
                   "method": "rocprofv3 --pmc, separate passes (tools/pmc_step_traffic.sh); " + how + "; writes = 64*WRREQ_64B + 32*(WRREQ-WRREQ_64B); "

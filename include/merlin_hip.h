@@ -245,14 +245,17 @@ int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w, float eps,
 /* The q|k|v projection of one decode step in ONE launch: optional input_layernorm (norm_w, may be NULL), projection with 16-bit weights W
  * [3 H D, K] or (W == NULL) fp8 weights q8 + scales, rotate-half RoPE of q and k at pos[m] (llama_flash_attn_monkey_patch.py:56-59 on one
  * token) and the append of k, v to kcache / vcache [M, Smax, H D] at row pos[m].  qkv [M, 3 H D] gets the rotated q, k and v.  Equal to
- * mh_rmsnorm_fwd + mh_gemv (mh_gemv_fp8w) + mh_decode_rope_append bit for bit.  M <= 8, K <= 8192. */
+ * mh_rmsnorm_fwd + mh_gemv (mh_gemv_fp8w) + mh_decode_rope_append bit for bit.  M <= 8, K <= 8192.
+ * rope_pos (NULL = pos): rotary position of the new token when it differs from its cache row - prompts with padding in front of or
+ * inside them keep only their valid keys in the cache (rows 0..count-1) while positions stay absolute, as HF's LlamaModel numbers them
+ * when no position_ids are passed (llama_mmgpt.py:114-134 passes none). */
 int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, const void* q8, const float* scales,
-                     void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache,
-                     int H, int D, int Smax, void* stream);
-/* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position pos[b] (int32, device), copy k and v into
+                     void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos, const int32_t* rope_pos,
+                     void* kcache, void* vcache, int H, int D, int Smax, void* stream);
+/* qkv [B, 3, H, D] of the new tokens: rotate q and k in place at position rope_pos[b] (int32, device; NULL = pos), copy k and v into
  * kcache / vcache [B, Smax, H*D] at row pos[b]. */
-int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B, int H,
-                          int D, int Smax, int dt, void* stream);
+int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, const int32_t* rope_pos, void* kcache, void* vcache, int B,
+                          int H, int D, int Smax, int dt, void* stream);
 /* out[b, h*D..] = softmax(q[b,h] . K[b, 0..lens[b]) / sqrt(D)) V[b, 0..lens[b]);  q row stride ldq; D in {64, 128}.
  * Split-KV: with ws != NULL (B*H*mh_attn_decode_splits(B,H,Smax)*(D+2) floats) several blocks share one (b, h) and a
  * second pass merges their partial softmaxes; ws == NULL runs one block per (b, h). */
@@ -273,7 +276,7 @@ int mh_select_tokens(const float* logits, int64_t ldl, int rows, int V, int do_s
 /* out[r, :V] = log_softmax(logits[r, :V]) + row_bias[r] (fp32; row_bias nullable): beam search's accumulated scores
  * log_probs + running_beam_scores (transformers/generation/utils.py `_beam_search`) */
 int mh_log_softmax_rows(const float* logits, int64_t ldl, int rows, int V, float* out, int64_t ldo, const float* row_bias, void* stream);
-/* dst[i, :cols_bytes] = src[idx[i], :cols_bytes]; row strides and cols in BYTES, multiples of 4 (16 for the fast path) (KV-cache reorder by
+/* dst[i, :cols_bytes] = src[idx[i], :cols_bytes], zeros where idx[i] < 0; row strides and cols in BYTES, multiples of 4 (16 for the fast path) (KV-cache reorder by
  * beam index = HF `_reorder_cache`; expansion of a prefilled batch to num_beams rows per prompt) */
 int mh_gather_rows2d(const void* src, int64_t lds_bytes, const int64_t* idx, void* dst, int64_t ldd_bytes, int rows, int64_t cols_bytes,
                      void* stream);
@@ -333,11 +336,17 @@ int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src,
 /* lens[b] = 1 + last s with mask[b, s] != 0 (mask: bool/uint8 [B, S]); the collator's right-padded
  * attention_mask (collator.py:32) -> per-sample lengths = flash-attn's cu_seqlens */
 int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream);
+/* unpad_input / pad_input of the key-padding branch (llama_flash_attn_monkey_patch.py:87-102; flash_attn.bert_padding) as row tables for
+ * mh_gather_rows2d: fwd[b*S + r] = flat row of the r-th valid position of sample b (-1 for r >= count[b]); inv[b*S + s] = b*S + rank of
+ * position s among the valid ones (-1 where mask is 0).  Valid tokens are compacted to the front of their own sample's S rows, so
+ * the attention kernels see a right-padded batch with lens = count: ANY mask (left padding, holes) runs, like the reference. */
+int mh_mask_unpad_index(const void* mask_u8, int64_t* fwd, int64_t* inv, int32_t* count, int B, int S, void* stream);
 /* Device-side validation of a batch (no host sync; the caller reads `err` back asynchronously):
  *   err[4]/err[5]: an input id outside [0, V) / its flat position      (reference: torch embedding raises IndexError)
  *   err[6]/err[7]: a label that is neither -100 nor in [0, V) / position (reference: CrossEntropyLoss target out of bounds)
- *   err[8]/err[9]: attention_mask of sample err[9] is not a right-padded prefix (popcount != lens[b]); this path implements
- *   the key-padding form of llama_flash_attn_monkey_patch.py:87-102 for right-padded batches (collator.py:29-34) only.
+ *   err[8]/err[9]: attention_mask of sample err[9] is not a right-padded prefix (popcount != lens[b]): not an error - the host then
+ *   routes attention through mh_mask_unpad_index's tables (general key-padding form of llama_flash_attn_monkey_patch.py:87-102)
+ *   instead of the lens-only fast path of right-padded batches (collator.py:29-34).
  * ids / labels / mask may each be NULL (skipped).  err is int32[10], shared with mh_splice_index (slots 0-3). */
 int mh_check_inputs(const int64_t* ids, const int64_t* labels, const void* mask_u8, const int32_t* lens, int32_t* err, int B, int S,
                     int V, void* stream);

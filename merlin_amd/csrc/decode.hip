@@ -36,7 +36,8 @@ __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
 // them at pos[m] (rotate-half, as rope_append_k on the stored 16-bit values) and write k / v straight into the cache rows [m, pos[m]].
 struct RopeAppend {
   const float2* tab;   // [max_pos, D/2] (cos, sin)
-  const int32_t* pos;  // [M]
+  const int32_t* pos;  // [M] cache row the new k, v are appended at
+  const int32_t* rpos; // [M] rotary position of the new token (== pos unless the prompt had padding in front of / inside it)
   uint16_t *kc, *vc;   // [M, Smax, H*D]
   int H, D, Smax;
 };
@@ -50,7 +51,7 @@ __device__ __forceinline__ void rope_append_store(const RopeAppend& ra, int pidx
     float lo = ld16<DT>((uint16_t)st16<DT>(a0[m])), hi = ld16<DT>((uint16_t)st16<DT>(a1[m]));  // the projection as it would be stored
     const int p = ra.pos[m];
     if (sec < 2) {
-      const float2 cs = ra.tab[(int64_t)p * half + c];
+      const float2 cs = ra.tab[(int64_t)ra.rpos[m] * half + c];
       rope_rot(lo, hi, cs.x, cs.y, lo, hi);
     }
     const uint16_t l16 = (uint16_t)st16<DT>(lo), h16 = (uint16_t)st16<DT>(hi);
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_k(const uint16_t* __restric
           const int half = ra.D >> 1, slot = n0 / ra.D, sec = slot / ra.H, c = n0 - slot * ra.D + j, p = ra.pos[m];
           const int64_t HD = (int64_t)ra.H * ra.D, col = (int64_t)(slot - sec * ra.H) * ra.D + c;
           if (sec < 2) {
-            const float2 cs = ra.tab[(int64_t)p * half + c];
+            const float2 cs = ra.tab[(int64_t)ra.rpos[m] * half + c];
             rope_rot(lo, hi, cs.x, cs.y, lo, hi);
           }
           const uint16_t l16 = (uint16_t)st16<DT>(lo), h16 = (uint16_t)st16<DT>(hi);
@@ -745,8 +746,8 @@ static int launch_gemv_mfma(const void* x, int64_t ldx, const void* W, int64_t l
 // qkv [B, 3, H, D] of the new tokens; tab [max_pos, D/2] (cos, sin); kc, vc [B, Smax, H*D]
 template <int DT>
 __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv, const float2* __restrict__ tab,
-                                                     const int32_t* __restrict__ pos, uint16_t* __restrict__ kc,
-                                                     uint16_t* __restrict__ vc, int B, int H, int D, int Smax) {
+                                                     const int32_t* __restrict__ pos, const int32_t* __restrict__ rpos,
+                                                     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int B, int H, int D, int Smax) {
   const int half = D >> 1, vph = half >> 3;
   const int64_t total = (int64_t)B * H * vph;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv,
   const int h = (int)((i / vph) % H);
   const int b = (int)(i / ((int64_t)vph * H));
   const int p = pos[b];
-  const float2* tb = tab + (int64_t)p * half + v * 8;
+  const float2* tb = tab + (int64_t)rpos[b] * half + v * 8;
   const int64_t hd = (int64_t)h * D + v * 8;
   uint16_t* qb = qkv + (int64_t)b * 3 * H * D + hd;
   uint16_t* kb = qb + (int64_t)H * D;
@@ -1032,17 +1033,18 @@ extern "C" int mh_gemv_norm(const void* x, int64_t ldx, const void* norm_w, floa
 }
 
 
-extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, void* kcache, void* vcache, int B,
-                                     int H, int D, int Smax, int dt, void* stream) {
+extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, const int32_t* rope_pos, void* kcache, void* vcache,
+                                     int B, int H, int D, int Smax, int dt, void* stream) {
+  if (!rope_pos) rope_pos = pos;
   if (!qkv || !cos_sin || !pos || !kcache || !vcache || B <= 0 || H <= 0 || (D & 15) || Smax <= 0) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   const int64_t total = (int64_t)B * H * (D / 16);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (dt == MH_BF16)
-    hipLaunchKernelGGL(rope_append_k<MH_BF16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos,
+    hipLaunchKernelGGL(rope_append_k<MH_BF16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos, rope_pos,
                        (uint16_t*)kcache, (uint16_t*)vcache, B, H, D, Smax);
   else
-    hipLaunchKernelGGL(rope_append_k<MH_F16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos,
+    hipLaunchKernelGGL(rope_append_k<MH_F16>, grid, block, 0, as_stream(stream), (uint16_t*)qkv, (const float2*)cos_sin, pos, rope_pos,
                        (uint16_t*)kcache, (uint16_t*)vcache, B, H, D, Smax);
   MH_LAUNCH_CHECK();
 }
@@ -1185,10 +1187,10 @@ extern "C" int mh_gemv_fp8w_norm(const void* x, int64_t ldx, const void* norm_w,
 // (= mh_rmsnorm_fwd + mh_gemv / mh_gemv_fp8w + mh_decode_rope_append, bit for bit).  qkv [M, 3 H D] receives the rotated q, k and v.
 extern "C" int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, const void* q8,
                                 const float* scales, void* qkv, int64_t ldo, int M, int K, int dt, const float* cos_sin, const int32_t* pos,
-                                void* kcache, void* vcache, int H, int D, int Smax, void* stream) {
+                                const int32_t* rope_pos, void* kcache, void* vcache, int H, int D, int Smax, void* stream) {
   if (!cos_sin || !pos || !kcache || !vcache || H <= 0 || D <= 0 || (D & 1) || Smax <= 0 || (!W && !(q8 && scales))) return MH_ERR_ARG;
   RopeAppend ra;
-  ra.tab = (const float2*)cos_sin; ra.pos = pos; ra.kc = (uint16_t*)kcache; ra.vc = (uint16_t*)vcache; ra.H = H; ra.D = D; ra.Smax = Smax;
+  ra.tab = (const float2*)cos_sin; ra.pos = pos; ra.rpos = rope_pos ? rope_pos : pos; ra.kc = (uint16_t*)kcache; ra.vc = (uint16_t*)vcache; ra.H = H; ra.D = D; ra.Smax = Smax;
   const int N = 3 * H * D;
   if (W) return gemv_impl(x, ldx, W, ldw, qkv, ldo, nullptr, 0, M, N, K, dt, 0, 0, norm_w, eps, ra, stream);
   return gemv_fp8w_impl(x, ldx, q8, scales, qkv, ldo, nullptr, 0, M, N, K, dt, 0, 0, norm_w, eps, ra, stream);

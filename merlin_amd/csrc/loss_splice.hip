@@ -215,9 +215,47 @@ __global__ __launch_bounds__(256) void mask_lens_k(const uint8_t* __restrict__ m
   if (threadIdx.x == 0) lens[b] = max(max(best[0], best[1]), max(best[2], best[3]));
 }
 
+// unpad_input / pad_input of the flash-attention patch (llama_flash_attn_monkey_patch.py:87-102, flash_attn.bert_padding) as two row
+// tables per sample, built by one block with a block-wide exclusive scan over the mask (order-preserving, deterministic):
+//   fwd[b*S + r] = flat row of the r-th valid position of sample b (r < count[b]), -1 beyond   (unpad: compact = gather(x, fwd))
+//   inv[b*S + s] = b*S + rank of position s among the valid ones, -1 where the mask is 0        (pad:   x = gather(compact, inv))
+// The valid tokens of a sample are compacted to the FRONT OF ITS OWN S-row slot, so the attention kernels run on them as a right-padded
+// batch with lens = count (causal order among valid tokens = the reference's causal attention over the packed sequence).
+__global__ __launch_bounds__(256) void mask_unpad_index_k(const uint8_t* __restrict__ mask, int64_t* __restrict__ fwd, int64_t* __restrict__ inv,
+                                                          int32_t* __restrict__ count, int S) {
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (S + 255) / 256, s0 = tid * per, s1 = min(S, s0 + per);
+  const uint8_t* m = mask + (int64_t)b * S;
+  int c = 0;
+  for (int s = s0; s < s1; ++s) c += m[s] ? 1 : 0;
+  part[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int r = part[tid] - c;  // exclusive prefix of this thread's chunk
+  const int total = part[255];
+  const int64_t base = (int64_t)b * S;
+  for (int s = s0; s < s1; ++s) {
+    if (m[s]) {
+      fwd[base + r] = base + s;
+      inv[base + s] = base + r;
+      ++r;
+    } else {
+      inv[base + s] = -1;
+    }
+  }
+  for (int s = total + tid; s < S; s += 256) fwd[base + s] = -1;
+  if (tid == 0) count[b] = total;
+}
+
 // Input validation on the device (one block per sample, no host sync): the reference raises on these through torch itself
-// (embedding index out of range, CE target out of bounds) and honours arbitrary masks; this path supports right-padded masks
-// only (lens), so anything else must fail loudly instead of being read as a dense prefix.
+// (embedding index out of range, CE target out of bounds) and honours arbitrary masks: a mask that is not a right-padded prefix is
+// FLAGGED here (err[8]) and the host then routes attention through the unpad / pad tables above instead of the lens-only fast path.
 //   err[4] = 1: an input id outside [0, V)      (err[5] = flat position)
 //   err[6] = 1: a label that is neither -100 nor in [0, V)   (err[7] = flat position)
 //   err[8] = 1: attention_mask of sample err[9] is not a right-padded prefix (popcount != 1 + last set position)
@@ -306,6 +344,12 @@ extern "C" int mh_splice_index(const int64_t* ids, const int32_t* img_offset, in
 extern "C" int mh_mask_lens(const void* mask_u8, int32_t* lens, int B, int S, void* stream) {
   if (!mask_u8 || !lens || B <= 0 || S <= 0) return MH_ERR_ARG;
   hipLaunchKernelGGL(mask_lens_k, dim3(B), dim3(256), 0, as_stream(stream), (const uint8_t*)mask_u8, lens, S);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_mask_unpad_index(const void* mask_u8, int64_t* fwd, int64_t* inv, int32_t* count, int B, int S, void* stream) {
+  if (!mask_u8 || !fwd || !inv || !count || B <= 0 || S <= 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(mask_unpad_index_k, dim3(B), dim3(256), 0, as_stream(stream), (const uint8_t*)mask_u8, fwd, inv, count, S);
   MH_LAUNCH_CHECK();
 }
 

@@ -5,7 +5,8 @@
 //   mh_select_tokens   argmax (do_sample=0) or temperature -> top-k -> top-p -> multinomial (inverse CDF in index order; the
 //                      uniform comes from a counter-based generator keyed on (seed, step, row): no host RNG traffic, replayable)
 //   mh_log_softmax_rows  fp32 log-probabilities for beam search
-//   mh_gather_rows2d   dst[i, :cols] = src[idx[i], :cols]  (KV-cache reorder by beam index, batch expansion)
+//   mh_gather_rows2d   dst[i, :cols] = src[idx[i], :cols], zeros where idx[i] < 0  (KV-cache reorder by beam index, batch expansion,
+//                      unpad / pad of the key-padding attention branch)
 #include "mh_common.h"
 
 namespace {
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(256) void gather_rows2d_k(const VT* __restrict__ sr
   const int64_t total = (int64_t)rows * cols_v;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / cols_v, c = i - r * cols_v;
-    dst[r * ldd_v + c] = src[idx[r] * lds_v + c];
+    const int64_t sr = idx[r];  // < 0: a zero row (pad_input of the key-padding branch: rows no valid token maps to)
+    VT val = VT{};
+    if (sr >= 0) val = src[sr * lds_v + c];
+    dst[r * ldd_v + c] = val;
   }
 }
 

@@ -181,9 +181,13 @@ def _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, p
     graph = None
     if use_graph and logits.is_cuda and max_new > 2:
         graph, g_tok, g_logits = eng.capture_decode_graph(cache, fp8=fp8_weights)  # the decode step as one replayable HIP graph
-    padded = attention_mask is not None and not bool(attention_mask.to(torch.bool).all())
+    am = attention_mask.to(dev).to(torch.bool) if attention_mask is not None else None
+    # right-padded prompts (ones then zeros; an extension - HF wants left padding): each row continues from its own length.
+    # Anything else (HF's left padding, holes) follows transformers: new tokens are appended after the padded prompt, keys are the
+    # valid positions only, rotary positions stay absolute (the engine's unpad / pad attention path + compacted KV cache).
+    padded = am is not None and not bool(am.all()) and bool((am[:, 1:] <= am[:, :-1]).all())
     ids = input_ids.to(dev)
-    lens = attention_mask.to(dev).to(torch.bool).sum(dim=1) if padded else None
+    lens = am.sum(dim=1) if padded else None
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)
     new = []
     for step in range(max_new):

@@ -54,6 +54,7 @@ class HipEngine:
         self.on_backward_begin = None  # callable(fresh: bool) | None
         self.strict_checks = True
         self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
+        self.force_unpad = False  # tests: send right-padded masks through the general unpad / pad attention path as well
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -413,22 +414,64 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     # Llama
     # ------------------------------------------------------------------------------------------
-    def _llama_layer_fwd(self, W, x, B, S, lens, keep, kv_out=None):
+    def _llama_layer_fwd(self, W, x, B, S, lens, keep, kv_out=None, unpad=None):
         cfg = self.model.config
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         h1 = O.rmsnorm_fwd(x, W.ln1, eps)
         qkv = O.gemm_nt_rope(h1, W.wqkv, self.rope, S, H, D)  # q|k|v projection with RoPE in the GEMM epilogue
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        if kv_out is not None:  # prefill: rotated keys and values go to the decode cache [B, Smax, d]
-            kv_out[0][:, :S].copy_(k.view(B, S, d))
-            kv_out[1][:, :S].copy_(v.view(B, S, d))
-        o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+        o, lse, packed = self._attn_fwd(qkv, B, S, H, D, lens, unpad, kv_out)
         x2 = O.gemm_nt(o, W.wo, resid=x)
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
         gu, act = O.gemm_swiglu_fwd(h2, W.wgu)  # gate|up projection; SwiGLU in the same launch's epilogue
         y = O.gemm_nt(act, W.wd, resid=x2)
-        return y, ((h1, qkv, o, lse, x2, h2, gu, act) if keep else None)
+        return y, ((h1, qkv, o, lse, x2, h2, gu, act, packed) if keep else None)
+
+    # ---- attention under a key-padding mask (llama_flash_attn_monkey_patch.py:87-102) ---------------------------------------------
+    # Right-padded batches (the collator's, collator.py:29-34) only need per-sample lengths: the kernels skip keys >= lens[b] and
+    # zero the padded query rows.  Any other mask takes the reference's own route: unpad_input (gather the valid rows of the ROTATED
+    # q|k|v - positions stay absolute, RoPE ran in the projection's epilogue) -> causal varlen attention over the packed tokens ->
+    # pad_input (scatter back, zeros elsewhere), with the same two gathers around the backward.
+    def _attn_fwd(self, qkv, B, S, H, D, lens, unpad, kv_out=None):
+        d = H * D
+        if unpad is None:
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            if kv_out is not None:  # prefill: rotated keys and values go to the decode cache [B, Smax, d]
+                kv_out[0][:, :S].copy_(k.view(B, S, d))
+                kv_out[1][:, :S].copy_(v.view(B, S, d))
+            o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+            return o, lse, None
+        fwd, inv, cnt = unpad
+        qkv_c = O.gather_rows2d(qkv, fwd, torch.empty_like(qkv))
+        q, k, v = qkv_c[:, :d], qkv_c[:, d:2 * d], qkv_c[:, 2 * d:]
+        if kv_out is not None:  # the cache keeps only the VALID keys (rows 0..count-1); their rotation already carries the position
+            kv_out[0][:, :S].copy_(k.view(B, S, d))
+            kv_out[1][:, :S].copy_(v.view(B, S, d))
+        o_c, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=cnt)
+        o = O.gather_rows2d(o_c, inv, torch.empty_like(o_c))
+        return o, lse, (qkv_c, o_c)
+
+    def _attn_bwd(self, qkv, o, do, lse, B, S, H, D, lens, unpad, packed):
+        """-> dqkv [T, 3 H D] w.r.t. the UN-rotated q, k (inverse RoPE applied)."""
+        d = H * D
+        dqkv = torch.empty_like(qkv)
+        if unpad is None:
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:],
+                        rope=self.rope)  # inverse RoPE of dq, dk fused into the kernels' epilogues
+            return dqkv
+        fwd, inv, cnt = unpad
+        if packed is None:  # (layer recompute dropped them)
+            qkv_c = O.gather_rows2d(qkv, fwd, torch.empty_like(qkv))
+            o_c = O.gather_rows2d(o, fwd, torch.empty_like(o))
+        else:
+            qkv_c, o_c = packed
+        do_c = O.gather_rows2d(do, fwd, torch.empty_like(do))
+        q, k, v = qkv_c[:, :d], qkv_c[:, d:2 * d], qkv_c[:, 2 * d:]
+        dqkv_c = torch.empty_like(qkv)
+        O.attn_bwd2(q, k, v, o_c, do_c, lse, B, S, H, D, True, seqlens=cnt, dq=dqkv_c[:, :d], dk=dqkv_c[:, d:2 * d], dv=dqkv_c[:, 2 * d:])
+        O.gather_rows2d(dqkv_c, inv, dqkv)
+        return O.rope_qk_(dqkv, self.rope, S, H, D, inverse=True)  # positions are those of the UNPACKED rows
 
     def quantize_forward_weights(self):
         """fp8 (e4m3, one scale per output channel) copies of the decoder's Linear weights for the fp8 FORWARD (inference /
@@ -438,7 +481,7 @@ class HipEngine:
                               wd=O.quant_fp8_rows_e4(W.wd)) for W in self.llama]
         return self._fp8_fwd
 
-    def _llama_layer_fwd_fp8(self, W, Q, x, B, S, lens, kv_out=None):
+    def _llama_layer_fwd_fp8(self, W, Q, x, B, S, lens, kv_out=None, unpad=None):
         """Decoder layer with every Linear on the scaled-fp8 MFMA: activations are quantised per token row right before
         each GEMM (dynamic scaling), weights per output channel (once); residual stream, norms, RoPE, attention and
         SwiGLU stay 16-bit.  Forward only."""
@@ -447,11 +490,7 @@ class HipEngine:
         eps = cfg.rms_norm_eps
         _, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)
         qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        if kv_out is not None:
-            kv_out[0][:, :S].copy_(k.view(B, S, d))
-            kv_out[1][:, :S].copy_(v.view(B, S, d))
-        o, _ = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+        o, _, _ = self._attn_fwd(qkv, B, S, H, D, lens, unpad, kv_out)
         x2 = O.gemm_fp8(O.quant_fp8_rows(o), Q["wo"], out_dtype=x.dtype, resid=x)
         _, a3 = O.rmsnorm_fwd_q8(x2, W.ln2, eps)
         _, act = O.gemm_fp8_swiglu_fwd(a3, Q["wgu"], out_dtype=x.dtype)
@@ -474,15 +513,14 @@ class HipEngine:
             return out
         return self._derive("fp8_train_weights", make)[li]
 
-    def _llama_layer_fwd_fp8_train(self, W, li, x, B, S, lens, keep):
+    def _llama_layer_fwd_fp8_train(self, W, li, x, B, S, lens, keep, unpad=None):
         cfg = self.model.config
         d, H, D = cfg.hidden_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         Q = self.fp8_train_weights(li)
         h1, a1 = O.rmsnorm_fwd_q8(x, W.ln1, eps)  # norm + row quantisation of its output in one launch
         qkv = O.gemm_fp8_rope(a1, Q["wqkv"], self.rope, S, H, D, out_dtype=x.dtype)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=True, seqlens=lens)
+        o, lse, packed = self._attn_fwd(qkv, B, S, H, D, lens, unpad)
         a2 = O.quant_fp8_rows(o)
         x2 = O.gemm_fp8(a2, Q["wo"], out_dtype=x.dtype, resid=x)
         h2, a3 = O.rmsnorm_fwd_q8(x2, W.ln2, eps)
@@ -490,7 +528,7 @@ class HipEngine:
         a4 = O.quant_fp8_rows(act)
         y = O.gemm_fp8(a4, Q["wd"], out_dtype=x.dtype, resid=x2)
         # the row scales (one float per token) are kept: their maximum is the tensor-wide scale of the transposed wgrad operand
-        return y, ((h1, qkv, o, lse, x2, h2, gu, act, (a1[1], a2[1], a3[1], a4[1])) if keep else None)
+        return y, ((h1, qkv, o, lse, x2, h2, gu, act, (a1[1], a2[1], a3[1], a4[1]), packed) if keep else None)
 
     def _wgrad_fp8(self, dyT8, x, sx, gout, fresh):
         """gout[N_out, K_in] (+)= dy^T x on the scaled-fp8 MFMA: both operands as transposed e4m3 copies (contraction over the
@@ -501,14 +539,14 @@ class HipEngine:
         tensor-wide scale = the largest of the row scales its forward quantisation already produced (single pass)."""
         O.gemm_fp8(dyT8, O.quant_fp8_t_from_rows(x, sx), out=gout, accum=not fresh)
 
-    def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh):
+    def _llama_layer_bwd_fp8(self, W, li, x, dy, B, S, lens, saved, fresh, unpad=None):
         cfg = self.model.config
         A = self.arena
         d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         if saved is None:
-            _, saved = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=True)
-        h1, qkv, o, lse, x2, h2, gu, act, (s_h1, s_o, s_h2, s_act) = saved
+            _, saved = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=True, unpad=unpad)
+        h1, qkv, o, lse, x2, h2, gu, act, (s_h1, s_o, s_h2, s_act), packed = saved
         Q = self.fp8_train_weights(li)
         p = W.p
         acc = not fresh
@@ -531,9 +569,7 @@ class HipEngine:
         if train:
             self._wgrad_fp8(dx2T8, o, s_o, A.gview(p + "self_attn.o_proj.weight"), fresh)
         del dx28, dx2T8
-        dqkv = torch.empty_like(qkv)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:], rope=self.rope)
+        dqkv = self._attn_bwd(qkv, o, do, lse, B, S, H, D, lens, unpad, packed)
         dqkv8, dqkvT8 = O.quant_fp8_both(dqkv) if train else (O.quant_fp8_rows(dqkv), None)
         dh1 = O.gemm_fp8(dqkv8, Q["wqkvT"], out_dtype=dt)
         if train:
@@ -544,14 +580,14 @@ class HipEngine:
             self._ready(W.names)
         return dx
 
-    def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh):
+    def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh, unpad=None):
         cfg = self.model.config
         A = self.arena
         d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
         if saved is None:
-            _, saved = self._llama_layer_fwd(W, x, B, S, lens, keep=True)
-        h1, qkv, o, lse, x2, h2, gu, act = saved
+            _, saved = self._llama_layer_fwd(W, x, B, S, lens, keep=True, unpad=unpad)
+        h1, qkv, o, lse, x2, h2, gu, act, packed = saved
         T = x.shape[0]
         Tpad = _ru(T, 64)
         p = W.p
@@ -570,10 +606,7 @@ class HipEngine:
         do = O.gemm_nt(dx2, W.wo, b_t=True)
         if train:
             self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
-        dqkv = torch.empty_like(qkv)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:],
-                    rope=self.rope)  # inverse RoPE of dq, dk fused into the kernels' epilogues
+        dqkv = self._attn_bwd(qkv, o, do, lse, B, S, H, D, lens, unpad, packed)
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
             self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
@@ -587,8 +620,10 @@ class HipEngine:
     # splice / head
     # ------------------------------------------------------------------------------------------
     def _check_errors(self):
+        """Reads the device-side validation flags back (raises like the reference would) and returns True when the attention
+        mask is NOT a right-padded prefix (left padding, holes): the caller then takes the unpad / pad attention path."""
         if self._err is None:
-            return
+            return False
         err, ev = self._err
         self._err = None
         ev.synchronize()
@@ -601,9 +636,7 @@ class HipEngine:
             raise IndexError(f"index out of range in self: input_ids holds an id outside [0, vocab_size) at flat position {e[5]}")
         if e[6]:
             raise IndexError(f"Target out of bounds: labels holds a value that is neither -100 nor in [0, vocab_size) at flat position {e[7]}")
-        if e[8]:
-            raise ValueError(f"attention_mask of sample {e[9]} is not right-padded (ones followed by zeros): the HIP path implements the "
-                             "key-padding branch of the flash-attention patch for right-padded batches (collator.py:29-34) only")
+        return bool(e[8])
 
     def _splice_geometry(self):
         """(rows per image in the projector output, first patch row, P = image tokens per image) from the configs alone, so the
@@ -687,7 +720,11 @@ class HipEngine:
             feats, rpi, row0, P = self.projector(xt, N, Sv, ctx)
             assert (rpi, row0, P) == self._splice_geometry()
             ctx.update(src=src, n_feat_rows=feats.shape[0])
-        self._check_errors()  # the flags were produced before the tower was enqueued: no wait for compute
+        general_mask = self._check_errors()  # the flags were produced before the tower was enqueued: no wait for compute
+        unpad = None
+        if attention_mask is not None and (general_mask or self.force_unpad):
+            unpad = O.mask_unpad_index(am.contiguous())
+        ctx["unpad"] = unpad
         if inputs_embeds is not None:
             x = inputs_embeds.to(device=dev, dtype=dt).reshape(T, d).contiguous()
         else:
@@ -711,18 +748,18 @@ class HipEngine:
                     raise RuntimeError("prefill runs the 16-bit or fp8-forward path")
                 if want_grad:
                     xs.append(x)
-                x, sv = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=want_grad and self.save_activations)
+                x, sv = self._llama_layer_fwd_fp8_train(W, li, x, B, S, lens, keep=want_grad and self.save_activations, unpad=unpad)
                 saves.append(sv)
                 continue
             if fp8:
                 x = self._llama_layer_fwd_fp8(W, F8[li], x, B, S, lens,
-                                              kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None)
+                                              kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad)
                 saves.append(None)
                 continue
             if want_grad:
                 xs.append(x)
             x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations,
-                                          kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None)
+                                          kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad)
             saves.append(sv)
         ctx.update(xs=xs, saves=saves, x_last=x if want_grad else None)
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), cfg.rms_norm_eps)
@@ -785,9 +822,9 @@ class HipEngine:
         # ---- decoder ----
         for i in reversed(range(len(self.llama))):
             if ctx.get("fp8_train"):
-                dx = self._llama_layer_bwd_fp8(self.llama[i], i, ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
+                dx = self._llama_layer_bwd_fp8(self.llama[i], i, ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh, unpad=ctx.get("unpad"))
             else:
-                dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh)
+                dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh, unpad=ctx.get("unpad"))
             ctx["xs"][i] = None
             ctx["saves"][i] = None
         # ---- embedding + splice ----
@@ -854,6 +891,9 @@ class HipEngine:
             self.k = [torch.zeros(B, Smax, d, dtype=dtype, device=device) for _ in range(n_layers)]
             self.v = [torch.zeros(B, Smax, d, dtype=dtype, device=device) for _ in range(n_layers)]
             self.lens = torch.zeros(B, dtype=torch.int32, device=device)
+            # rotary position of the next token when it differs from its cache row (prompts with padding in front of / inside
+            # them keep only their valid keys, positions stay absolute as HF numbers them); None: == lens
+            self.rpos = None
             self.B, self.Smax = B, Smax
             self.k_alt = self.v_alt = None
 
@@ -869,7 +909,13 @@ class HipEngine:
         _, logits, ctx = self.forward(input_ids, attention_mask, None, images, inputs_embeds=inputs_embeds, kv_cache=cache,
                                       last_only=True)
         lens = ctx["lens"]
-        cache.lens.copy_(lens if lens is not None else torch.full((B,), S, dtype=torch.int32, device=A.flat.device))
+        if ctx.get("unpad") is not None:
+            # general mask (left padding / holes): the cache holds the valid keys only; the next token's rotary position is the
+            # padded prompt length, as LlamaModel numbers it when generate() passes no position_ids (llama_mmgpt.py:114-134)
+            cache.lens.copy_(ctx["unpad"][2])
+            cache.rpos = torch.full((B,), S, dtype=torch.int32, device=A.flat.device)
+        else:
+            cache.lens.copy_(lens if lens is not None else torch.full((B,), S, dtype=torch.int32, device=A.flat.device))
         return logits, cache
 
     def expand_cache(self, cache, rows):
@@ -885,6 +931,7 @@ class HipEngine:
                 O.gather_rows2d(src_l[li].view(cache.B, Smax * d), rows, dst.view(n, Smax * d))
                 dst_l.append(dst)
         out.lens = cache.lens.index_select(0, rows).contiguous()  # B int32 values, once per generate() call
+        out.rpos = cache.rpos.index_select(0, rows).contiguous() if cache.rpos is not None else None
         return out
 
     def reorder_cache(self, cache, beam_idx, n_valid):
@@ -932,7 +979,7 @@ class HipEngine:
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
             # input_layernorm + q|k|v projection + RoPE + K/V append: one launch
-            qkv = O.gemv_qkv_rope(x, W.ln1, eps, W.wqkv, self.rope, pos, cache.k[li], cache.v[li], H, D)
+            qkv = O.gemv_qkv_rope(x, W.ln1, eps, W.wqkv, self.rope, pos, cache.k[li], cache.v[li], H, D, rope_pos=cache.rpos)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv(o, W.wo, resid=x)
             act = O.gemv_norm(x2, W.ln2, eps, W.wgu, swiglu=True)  # post_attention_layernorm + gate|up + SwiGLU: one launch
@@ -942,6 +989,8 @@ class HipEngine:
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
         logits = O.gemv(hn, wlm, out_f32=True, n=V)
         cache.lens.add_(1)  # in place (after every kernel that read it as `pos`): the captured graph sees the same buffer
+        if cache.rpos is not None:
+            cache.rpos.add_(1)
         return logits
 
     def _decode_step_fp8(self, tokens, cache):
@@ -956,7 +1005,7 @@ class HipEngine:
         lens1 = pos + 1
         for li, W in enumerate(self.llama):
             Q = F8["layers"][li]
-            qkv = O.gemv_qkv_rope(x, W.ln1, eps, Q["wqkv"], self.rope, pos, cache.k[li], cache.v[li], H, D)
+            qkv = O.gemv_qkv_rope(x, W.ln1, eps, Q["wqkv"], self.rope, pos, cache.k[li], cache.v[li], H, D, rope_pos=cache.rpos)
             o = O.attn_decode(qkv[:, :d], cache.k[li], cache.v[li], lens1, H, D)
             x2 = O.gemv_fp8w(o, Q["wo"], resid=x)
             act = O.gemv_fp8w_norm(x2, W.ln2, eps, Q["wgu"], swiglu=True)
@@ -964,6 +1013,8 @@ class HipEngine:
         hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), eps)
         logits = O.gemv_fp8w(hn, F8["lm_head"], out_f32=True)
         cache.lens.add_(1)
+        if cache.rpos is not None:
+            cache.rpos.add_(1)
         return logits
 
     def capture_decode_graph(self, cache, fp8=False):
@@ -974,16 +1025,21 @@ class HipEngine:
         dev = self.arena.flat.device
         tok = torch.zeros(cache.B, dtype=torch.int64, device=dev)
         keep = cache.lens.clone()
+        keep_r = cache.rpos.clone() if cache.rpos is not None else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             self.decode_step(tok, cache, fp8=fp8)
         torch.cuda.current_stream(dev).wait_stream(side)
         cache.lens.copy_(keep)
+        if keep_r is not None:
+            cache.rpos.copy_(keep_r)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             logits = self.decode_step(tok, cache, fp8=fp8)
         cache.lens.copy_(keep)  # capture does not execute, but keep the invariant explicit
+        if keep_r is not None:
+            cache.rpos.copy_(keep_r)
         return g, tok, logits
 
     # standalone sub-module calls (reference module surface; not used by the fused forward)

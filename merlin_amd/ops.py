@@ -233,7 +233,7 @@ def gemv_fp8w_norm(x, norm_w, eps, qw, swiglu=False, out=None):
     return out
 
 
-def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D):
+def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D, rope_pos=None):
     """Decode-step q|k|v: (input_layernorm +) projection + RoPE at pos + K/V append in one launch; w = 16-bit weight [3HD, K] or the
     (q, scales) pair of quant_fp8_b128.  Returns qkv [M, 3HD] (q, k rotated).  More than 16 rows: the separate launches."""
     M, K = x.shape
@@ -241,7 +241,7 @@ def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D):
     if not _gemv_fused_rows_ok(M, K) or K > 8192 or (M > 8 and (D // 2) % 16):
         h = rmsnorm_fwd(x, norm_w, eps)
         qkv = gemv_fp8w(h, w) if fp8 else gemv(h, w)
-        decode_rope_append(qkv, table, pos, kcache, vcache, H, D)
+        decode_rope_append(qkv, table, pos, kcache, vcache, H, D, rope_pos=rope_pos)
         return qkv
     if M > FUSED_NORM_MAX_ROWS:
         x, norm_w = rmsnorm_fwd(x, norm_w, eps), None
@@ -249,16 +249,18 @@ def gemv_qkv_rope(x, norm_w, eps, w, table, pos, kcache, vcache, H, D):
     qkv = torch.empty(M, 3 * H * D, dtype=x.dtype, device=x.device)
     wq, sc = (w if fp8 else (None, None))
     L.check(L.lib().mh_gemv_qkv_rope(p(x), i64(_rowmajor(x)), p(norm_w), f32(eps), p(None if fp8 else w), i64(0 if fp8 else _rowmajor(w)), p(wq), p(sc),
-                                     p(qkv), i64(_rowmajor(qkv)), i32(M), i32(K), i32(dt_of(x)), p(table), p(pos), p(kcache), p(vcache),
+                                     p(qkv), i64(_rowmajor(qkv)), i32(M), i32(K), i32(dt_of(x)), p(table), p(pos), p(rope_pos), p(kcache), p(vcache),
                                      i32(H), i32(D), i32(kcache.shape[1]), _stream()), "mh_gemv_qkv_rope")
     return qkv
 
 
-def decode_rope_append(qkv, table, pos, kcache, vcache, H, D):
-    """qkv [B, 3*H*D] of the new tokens (rotated in place at pos[b]); k, v appended to kcache/vcache [B, Smax, H*D]."""
+def decode_rope_append(qkv, table, pos, kcache, vcache, H, D, rope_pos=None):
+    """qkv [B, 3*H*D] of the new tokens (rotated in place at rope_pos[b], default pos[b]); k, v appended to kcache/vcache [B, Smax, H*D]
+    at row pos[b]."""
     B = qkv.shape[0]
     assert qkv.is_contiguous() and pos.dtype == torch.int32 and kcache.is_contiguous() and vcache.is_contiguous()
-    L.check(L.lib().mh_decode_rope_append(p(qkv), p(table), p(pos), p(kcache), p(vcache), i32(B), i32(H), i32(D),
+    assert rope_pos is None or rope_pos.dtype == torch.int32
+    L.check(L.lib().mh_decode_rope_append(p(qkv), p(table), p(pos), p(rope_pos), p(kcache), p(vcache), i32(B), i32(H), i32(D),
                                           i32(kcache.shape[1]), i32(dt_of(qkv)), _stream()), "mh_decode_rope_append")
 
 
@@ -829,6 +831,18 @@ def mask_lens(mask):
     lens = torch.empty(B, dtype=torch.int32, device=mask.device)
     L.check(L.lib().mh_mask_lens(p(mask), p(lens), i32(B), i32(S), _stream()), "mh_mask_lens")
     return lens
+
+
+def mask_unpad_index(mask):
+    """bool/uint8 mask [B, S] -> (fwd int64 [B*S], inv int64 [B*S], count int32 [B]): the unpad / pad row tables of the key-padding
+    attention branch (include/merlin_hip.h: mh_mask_unpad_index), consumed by gather_rows2d."""
+    B, S = mask.shape
+    assert mask.is_contiguous() and mask.element_size() == 1
+    fwd = torch.empty(B * S, dtype=torch.int64, device=mask.device)
+    inv = torch.empty(B * S, dtype=torch.int64, device=mask.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=mask.device)
+    L.check(L.lib().mh_mask_unpad_index(p(mask), p(fwd), p(inv), p(cnt), i32(B), i32(S), _stream()), "mh_mask_unpad_index")
+    return fwd, inv, cnt
 
 
 def check_inputs(ids, labels, mask, lens, err, V):

@@ -259,15 +259,11 @@ def test_device_side_input_validation_raises_like_torch():
     am = b["attention_mask"].clone()
     short = int(am.sum(1).argmin())
     n = int(am[short].sum())
-    am[short, 0] = False  # left padding / a hole: not a dense prefix any more
-    with pytest.raises(ValueError):
-        model(**dict(b, attention_mask=am))
-    am = b["attention_mask"].clone()
-    am[short, n - 2] = False
-    with pytest.raises(ValueError):
-        model(**dict(b, attention_mask=am))
+    am[short, n - 2] = False  # a hole: not a dense prefix any more -> the general unpad / pad attention path (tests/test_masks_gpu.py)
+    out_h = model(**dict(b, attention_mask=am))
+    assert bool(torch.isfinite(out_h.logits).all())
     model.engine.strict_checks = False
-    model(**dict(b, attention_mask=am))  # opt-out: treated as a dense prefix (documented)
+    model(**dict(b, attention_mask=am))  # opt-out of the device-side checks: treated as a dense prefix (documented)
     model.engine.strict_checks = True
     model(**b)
 

@@ -141,9 +141,14 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
                    void* stream);
 
-/* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip,
- * else 128x128), 128 or 256 = force that tile. */
+/* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip, else 128x128; among the
+ * 256x256 kernels the 4-wave form where mh_gemm_w4_policy says so), 128 = the 128x128 kernel, 256 = the 8-wave 256x256 kernel,
+ * 4 = the 4-wave 256x256 kernel (128x128 outputs per wave, csrc/gemm_w4.hip) wherever it can run. */
 void mh_gemm_force_kernel(int which);
+/* Operand layouts the auto selection gives to the 4-wave kernel when K >= 4096 and the epilogue is a plain (or accumulating)
+ * 16-bit store: bit 0 = TN (weight gradients: both operands K-strided), bit 1 = NN (dgrad), bit 2 = NT (forward; also with a
+ * residual).  Default 3 (measured: profiles/r03_gemm_w4_ab.txt). */
+void mh_gemm_w4_policy(int mask);
 /* 256x256-tile kernels: 1 (default) = persistent launch, one block per CU looping over the output tiles with the next tile's
  * first K-tile fetched under the epilogue; 0 = one block per tile (A-B benchmarks). */
 void mh_gemm_persistent(int on);

@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
             _lib.mh_gemm_persistent(C.c_int(0))
         if os.environ.get("MH_ATTN_BWD_FUSED_KV") == "0":
             _lib.mh_attn_bwd_fused_kv(C.c_int(0))
+        if os.environ.get("MH_W4_MASK"):  # layouts the auto selection gives to the 4-wave GEMM (bit 0 TN, 1 NN, 2 NT)
+            _lib.mh_gemm_w4_policy(C.c_int(int(os.environ["MH_W4_MASK"])))
         if os.environ.get("MH_GEMM_GM"):
             _lib.mh_gemm_raster_group(C.c_int(int(os.environ["MH_GEMM_GM"])))
     return _lib

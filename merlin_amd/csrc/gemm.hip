@@ -192,6 +192,17 @@ struct RopeSpec {
   const float* tab = nullptr; int S = 0, D = 0, cols = 0;
   int sw_mode = 0, sw_ff = 0; void* sw_out = nullptr; const void* sw_in = nullptr; int64_t sw_ldo = 0, sw_ldi = 0;  // fused SwiGLU
 };
+// Shapes that go to gemm_w4 by default (see the call site).  g_w4_mask: bit 0 = TN (wgrad), bit 1 = NN (dgrad), bit 2 = NT (measured: 3 is best in the step).
+int g_w4_mask = 3;
+extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
+static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi) {
+  const int form = (a_ks && b_ks) ? 1 : (b_ks ? 2 : (a_ks ? 0 : 4));
+  if (!(g_w4_mask & form)) return false;
+  (void)M; (void)N;
+  if (form == 4) return K >= 4096 && ((epi & ~MH_EPI_ACCUM) == 0 || (epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL);
+  return K >= 4096 && (epi & ~MH_EPI_ACCUM) == 0;
+}
+
 static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                      int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
                      int epilogue, int splits, int64_t c_split, void* stream, RopeSpec rope = RopeSpec());
@@ -429,14 +440,14 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
     g.tiles_n = (N + 255) / 256;
     return launch_gemm_nt_256_m32(g, dt, as_stream(stream));
   }
-  if (g_force_kernel >= 4 && g_force_kernel <= 12 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode &&
+  if (g_force_kernel >= 40 && g_force_kernel <= 48 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode &&
       (int64_t)M * lda * 2 < (1ll << 31) && (int64_t)N * ldb * 2 < (1ll << 31)) {  // A/B arm: four waves x 128x128 (gemm256w4.hip)
     const int e = epilogue;
     const bool known = e == 0 || e == MH_EPI_RESIDUAL || e == MH_EPI_BIAS || e == (MH_EPI_BIAS | MH_EPI_QUICK_GELU) || e == (MH_EPI_BIAS | MH_EPI_RESIDUAL);
     if (known && g.vec_ok && (N % 8 == 0) && (ldc % 8 == 0) && ((((uintptr_t)C) & 15u) == 0)) {  // staged epilogue only
       g.tiles_m = (M + 255) / 256;
       g.tiles_n = (N + 255) / 256;
-      return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 4);
+      return launch_gemm_nt_w4(g, dt, as_stream(stream), g_force_kernel - 40);
     }
   }
   if (g_force_kernel == 88 && !a_kstrided && !b_kstrided && splits == 1 && !rope.tab && !rope.sw_mode &&
@@ -450,6 +461,16 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
     }
   }
 #endif
+  // The 4-wave kernel (gemm_w4.hip: 128x128 per wave, a third fewer LDS bytes per flop) where it measures faster than the 8-wave
+  // one (profiles/r03_gemm_w4_ab.txt): K-strided weight gradients with a long token contraction.  mh_gemm_force_kernel(4) sends
+  // everything it can run there, (256) nothing.
+  {
+    g.tiles_m = (M + 255) / 256;
+    g.tiles_n = (N + 255) / 256;
+    const bool can = g_force_kernel != 256 && g_force_kernel != 128 && w4_can_run(g, a_kstrided, b_kstrided);
+    const bool want = g_force_kernel == 4 || (g_force_kernel == 0 && big && w4_policy(a_kstrided, b_kstrided, M, N, K, epilogue));
+    if (can && want) return launch_gemm_w4(g, dt, a_kstrided, b_kstrided, as_stream(stream));
+  }
   if (rope.sw_mode == 1) {  // a tile = 128 gate + 128 up columns
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = (rope.sw_ff + 127) / 128;

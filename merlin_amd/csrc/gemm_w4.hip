@@ -1,0 +1,404 @@
+// gemm_w4: 256x256x64-tile bf16/f16 MFMA GEMM with FOUR waves per block, one 128x128 output quadrant per wave (gfx950),
+// for all three operand layouts of the training step (NT forward, NN dgrad, TN wgrad; see gemm256.hip for the layouts).
+//
+// Why a second 256-tile kernel next to the 8-wave gemm_nt_256: the chip is power-capped (a register-only MFMA loop sustains
+// ~1.7 PFLOP/s, tools/probes/mfma_probe.hip), so what a main loop reaches is set by the energy it spends per flop besides the
+// MFMA itself.  With 8 waves a wave owns 128x64 outputs and a 32-deep k-step costs 12 fragment reads per 32 MFMAs; here a
+// wave owns 128x128 outputs = 64 accumulator tiles = 256 fp32 registers per lane, which fits because gfx950's register file
+// is 512 per lane at ONE wave per SIMD (accumulators in AccVGPRs, fragments in VGPRs): 16 fragment reads per 64 MFMAs = a
+// third fewer LDS bytes per flop, one barrier pair per K-tile instead of eight, and every non-MFMA instruction of the loop
+// (fragment read, M0 write, LDS-DMA copy) sits behind its own MFMA in a hand-placed stream.  Measured where it is dispatched
+// (profiles/r03_gemm_w4_ab.txt): the TN weight gradients (K = 32 768 tokens: the per-tile fixed cost does not matter and the
+// 8-wave kernel's transpose-read phases were its slowest form).  The 8-wave kernel keeps the fused-epilogue GEMMs (RoPE,
+// SwiGLU), split-K, K tails and the small / short-K shapes: half as many waves share this kernel's epilogue.
+//
+// LDS = two K-tile buffers of 64 KiB: [A part 32 KiB | B part 32 KiB].
+//   K-contiguous part: [256 rows][128 B]; 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128).
+//   K-strided part (memory is [K][M]): two half-tiles [64 k][128 m] (256-B rows); the 32-byte column chunk is XORed with
+//   f(k) = (k & 3) | ((k >> 3) & 1) << 2, fragments come from `ds_read_b64_tr_b16` transpose-reads (two per fragment).
+//   Copies are LDS-DMA (`buffer_load_dwordx4 ... lds`, lane-linear LDS image => both swizzles are applied to the SOURCE
+//   address); per-lane byte offsets are loop-invariant VGPRs and the K advance is the scalar offset: no VALU per copy.
+// Per K-tile t (fragment registers double-buffered per 32-deep k-step: set 0 = k 0..31, set 1 = k 32..63):
+//   phase E: 64 MFMAs on set 0 | read set 1 of tile t from buffer t&1; then lgkmcnt(0) + barrier B1 (every wave has all of
+//            tile t in registers: buffer t&1 is free) and the first copies of tile t+2 into buffer t&1
+//   phase O: 64 MFMAs on set 1 | vmcnt(CE) + barrier B2 (tile t+1 has landed for every wave; only the CE copies of tile t+2
+//            issued in phase E may still be in flight), the remaining copies of tile t+2, read set 0 of tile t+1.
+// The t loop is unrolled by the buffer parity so that every LDS address is a loop-invariant VGPR plus an immediate.
+#include <type_traits>
+
+#include "gemm_common.h"
+
+namespace mhgemm {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// MFMA with the accumulator pinned to AccVGPRs ("+a"): hipcc's allocator otherwise shuttles part of the 256 accumulators
+// between VGPRs and AccVGPRs inside the loop.  Volatile: the issue order below IS the schedule.
+template <int DT>
+__device__ __forceinline__ void mfma_acc(f32x4_t& c, const u32x4& a, const u32x4& b) {
+  if constexpr (DT == MH_BF16)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+constexpr int W4_PART = 256 * 128;     // 32 KiB: 256 rows x 64 k
+constexpr int W4_UNIT = 2 * W4_PART;   // A part + B part of one K-tile
+constexpr int W4_CSTAGE = 128 * 272;   // per-wave C staging slice of the epilogue (128 rows x (256 + 16) B)
+constexpr int W4_LDS = 4 * W4_CSTAGE;  // >= 2 * W4_UNIT: two K-tile buffers during the loop, four C slices after it
+
+template <int OFF>
+__device__ __forceinline__ void dsr128(u32x4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void dsr64tr(u32x2& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int N, typename F>
+__device__ __forceinline__ void w4_for(F&& f) {
+  if constexpr (N > 0) {
+    w4_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ---- the instruction schedule of a K-tile, as compile-time tables --------------------------------------------------------
+// NR = fragment-read instructions per phase: 8 per K-contiguous operand (ds_read_b128), 16 per K-strided one (two tr reads).
+template <int NR>
+struct Sched {
+  static constexpr int B1 = NR + 6;                                   // phase E: lgkmcnt(0) + barrier slot
+  static constexpr int E0 = NR + 8;                                   // phase E: first copy slot
+  static constexpr int PE = NR <= 16 ? 6 : (NR <= 24 ? 5 : 4);        // phase E: slots between copies
+  static constexpr int CE = (62 - E0) / PE + 1;                       // copies issued in phase E
+  static constexpr int O0 = 6, PO = 6;                                // phase O: first copy slot, spacing
+  static_assert(CE >= 1 && CE <= 15 && O0 + PO * (16 - CE - 1) + 1 <= 62, "copy schedule does not fit the phases");
+  static constexpr bool e_copy(int sl) { return sl >= E0 && (sl - E0) % PE < 2 && (sl - E0) / PE < CE; }
+  static constexpr int e_copy_index(int sl) { return (sl - E0) / PE; }
+  static constexpr bool o_copy(int sl) { return sl >= O0 && (sl - O0) % PO < 2 && (sl - O0) / PO < 16 - CE; }
+  static constexpr int o_copy_index(int sl) { return CE + (sl - O0) / PO; }
+  // phase O: fragment reads take the non-copy slots from 4 on, in order
+  static constexpr int o_read_index(int sl, bool loads) {
+    int n = 0;
+    for (int s = 4; s < sl; ++s) n += (loads && o_copy(s)) ? 0 : 1;
+    return n;
+  }
+};
+
+template <int DT, bool AKS, bool BKS>
+__global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = g.K / BK;
+  constexpr int NRA = AKS ? 16 : 8, NRB = BKS ? 16 : 8, NR = NRA + NRB;
+  using SC = Sched<NR>;
+
+  // ---- copies: per-lane source byte offsets (loop-invariant) and the wave's LDS destinations --------------------------------
+  // K-contiguous part: wave-load j (0..7) covers part rows 64*wave + 8j .. +7; lane i -> row + (i>>3), physical chunk i&7.
+  // K-strided part:    wave-load j covers half j>>2, 16-byte chunks qd = (j&3)*256 + 64*wave + lane of its [64 k][128 m] image.
+  int voffA[8], voffB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if constexpr (!AKS) {
+      const int row = wave * 64 + j * 8 + (lane >> 3);
+      voffA[j] = (int)((int64_t)min(m0 + row, g.M - 1) * g.lda * 2 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    } else {
+      const int qd = (j & 3) * 256 + wave * 64 + lane, k = qd >> 4, cc = qd & 15;
+      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+      voffA[j] = (int)(((int64_t)k * g.lda + min(m0 + (j >> 2) * 128 + col, g.M - 8)) * 2);
+    }
+    if constexpr (!BKS) {
+      const int row = wave * 64 + j * 8 + (lane >> 3);
+      voffB[j] = (int)((int64_t)min(n0 + row, g.N - 1) * g.ldb * 2 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    } else {
+      const int qd = (j & 3) * 256 + wave * 64 + lane, k = qd >> 4, cc = qd & 15;
+      const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
+      voffB[j] = (int)(((int64_t)k * g.ldb + min(n0 + (j >> 2) * 128 + col, g.N - 8)) * 2);
+    }
+  }
+  const int kstepA = AKS ? (int)((int64_t)BK * g.lda * 2) : BK * 2;  // source bytes per K-tile (host guarantees K * ld * 2 < 2^32)
+  const int kstepB = BKS ? (int)((int64_t)BK * g.ldb * 2) : BK * 2;
+  auto make_rs = [](const void* p_) {
+    const uint64_t a_ = (uint64_t)(uintptr_t)p_;
+    return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)a_),
+                 __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_ >> 32) & 0xffffu)), -1, 0x00020000};
+  };
+  const i32x4 rsA = make_rs(g.A), rsB = make_rs(g.B);
+  const unsigned lds0 = lds_addr_of(smem);
+  // the wave's share of a part starts at wave * 8 KiB (K-contiguous: 64 rows) or wave * 1 KiB inside each 4-KiB group (K-strided)
+  const unsigned w_kc = lds0 + (unsigned)wave * 8192u, w_ks = lds0 + (unsigned)wave * 1024u;  // (wave-uniform: SGPRs)
+  // the M0 write and the copy are separate single instructions, each placed behind its own MFMA
+  auto copy_m0 = [&](auto C_, auto BUF_) {
+    constexpr int c = decltype(C_)::value, bu = decltype(BUF_)::value, j = c & 7;
+    constexpr bool ks = c < 8 ? AKS : BKS;
+    constexpr int imm = bu * W4_UNIT + (c >> 3) * W4_PART + (ks ? (j >> 2) * 16384 + (j & 3) * 4096 : j * 1024);
+    const unsigned base_ = ks ? w_ks : w_kc;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(base_), "n"(imm) : "scc");
+  };
+  auto copy_ld = [&](auto C_, int t) {
+    constexpr int c = decltype(C_)::value;
+    const int vo = c < 8 ? voffA[c & 7] : voffB[c & 7];
+    const i32x4 rs = c < 8 ? rsA : rsB;
+    const unsigned soff = (unsigned)t * (unsigned)(c < 8 ? kstepA : kstepB);
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
+  };
+  auto issue_tile = [&](auto BUF_, int t) {  // prologue form (all 16 copies back to back)
+    w4_for<16>([&](auto C_) {
+      copy_m0(C_, BUF_);
+      copy_ld(C_, t);
+    });
+  };
+
+  using std::integral_constant;
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addresses (buffer 0 and buffer 1: loop-invariant VGPRs, everything else is an immediate) --------------------
+  const int fr = lane & 15, kq = lane >> 4;
+  const unsigned swz = (unsigned)((fr >> 1) & 7);
+  // K-contiguous: lane row inside the wave's 128 rows, k-step s chunk (4s + kq) ^ swz; fragment q = rows 16q.. = +2048 q
+  unsigned a_kc[2][2], b_kc[2][2];   // [buffer][k-step]
+  // K-strided: lane points at row k = 8*kq + (fr>>2), columns 4*(fr&3)..+3 of fragment q's 32-byte chunk (q ^ fx)
+  unsigned a_ks[2][8], b_ks[2][8];   // [buffer][fragment]
+  {
+    const unsigned t_rel = (unsigned)(kq * 8 + (fr >> 2)) * 256 + (unsigned)(fr & 3) * 8;
+    const unsigned fx = (unsigned)(fr >> 2) | ((unsigned)(kq & 1) << 2);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned ub = lds0 + (unsigned)b * W4_UNIT;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        a_kc[b][s] = ub + (unsigned)(wm * 128 + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
+        b_kc[b][s] = ub + W4_PART + (unsigned)(wn * 128 + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        a_ks[b][q] = ub + (unsigned)wm * 16384 + t_rel + (((unsigned)q ^ fx) << 5);
+        b_ks[b][q] = ub + W4_PART + (unsigned)wn * 16384 + t_rel + (((unsigned)q ^ fx) << 5);
+      }
+    }
+  }
+
+  u32x4 afc[2][8], bfc[2][8];                            // K-contiguous fragments [set][fragment]
+  u32x2 afl[2][8], afh[2][8], bfl[2][8], bfh[2][8];      // K-strided fragments: k 0..3 | 4..7 of the lane's 8 (two tr reads)
+
+    // fragment-read instruction r (0..NR-1) of k-step SET from buffer BUF: A's reads first, then B's
+  auto read1 = [&](auto BUF_, auto SET_, auto R_) {
+    constexpr int bu = decltype(BUF_)::value, s = decltype(SET_)::value, r = decltype(R_)::value;
+    if constexpr (r < NRA) {
+      if constexpr (!AKS) {
+        dsr128<r * 2048>(afc[s][r], a_kc[bu][s]);
+      } else {
+        constexpr int q = r >> 1;
+        if constexpr ((r & 1) == 0) dsr64tr<s * 8192>(afl[s][q], a_ks[bu][q]);
+        else dsr64tr<s * 8192 + 1024>(afh[s][q], a_ks[bu][q]);
+      }
+    } else {
+      constexpr int rb = r - NRA;
+      if constexpr (!BKS) {
+        dsr128<rb * 2048>(bfc[s][rb], b_kc[bu][s]);
+      } else {
+        constexpr int q = rb >> 1;
+        if constexpr ((rb & 1) == 0) dsr64tr<s * 8192>(bfl[s][q], b_ks[bu][q]);
+        else dsr64tr<s * 8192 + 1024>(bfh[s][q], b_ks[bu][q]);
+      }
+    }
+  };
+  // MFMA slot sl (0..63): accumulator (sl % 8, sl / 8).  The matrix core takes an independent 16x16x32 MFMA every 16 cycles and a
+  // wave issues in order, so with ONE wave per SIMD at most one other instruction may sit between two MFMAs.
+  auto mfma_slot = [&](auto SET_, auto SL_) {
+    constexpr int s = decltype(SET_)::value, sl = decltype(SL_)::value, i = sl % 8, j = sl / 8;
+    u32x4 a, b;
+    if constexpr (AKS) a = u32x4{afl[s][i][0], afl[s][i][1], afh[s][i][0], afh[s][i][1]};
+    else a = afc[s][i];
+    if constexpr (BKS) b = u32x4{bfl[s][j][0], bfl[s][j][1], bfh[s][j][0], bfh[s][j][1]};
+    else b = bfc[s][j];
+    mfma_acc<DT>(acc[i][j], b, a);  // operands swapped: the accumulator holds 4 consecutive n of one row m (vector epilogue)
+  };
+  using S0 = integral_constant<int, 0>;
+  using S1 = integral_constant<int, 1>;
+
+  // (tiles past the end: the copies re-fetch the LAST tile into a buffer nobody reads again - one uniform loop body, no tail variants:
+  // hipcc spills hundreds of registers around control flow that merges paths through these hand-placed asm streams)
+  auto phase_e = [&](auto BUF_, int t) {  // MFMAs on set 0 (tile t, k 0..31); fetch set 1 of tile t
+    constexpr bool loads = true;
+    const int tl = min(t + 2, nk - 1);
+    w4_for<64>([&](auto SL_) {
+      constexpr int sl = decltype(SL_)::value;
+      mfma_slot(S0{}, SL_);
+      if constexpr (sl < NR) read1(BUF_, S1{}, integral_constant<int, sl>{});
+      if constexpr (loads && sl == SC::B1) {  // every wave has all of tile t in registers -> buffer bu is free
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (loads && SC::e_copy(sl)) {
+        if constexpr ((sl - SC::E0) % SC::PE == 0) copy_m0(integral_constant<int, SC::e_copy_index(sl)>{}, BUF_);
+        else copy_ld(integral_constant<int, SC::e_copy_index(sl)>{}, tl);
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+  };
+  auto phase_o = [&](auto BUF_, int t) {  // MFMAs on set 1 (tile t, k 32..63); fetch set 0 of tile t+1
+    constexpr int bu = decltype(BUF_)::value;
+    constexpr bool loads = true;
+    const int tl = min(t + 2, nk - 1);
+    using NB = integral_constant<int, 1 - bu>;
+    w4_for<64>([&](auto SL_) {
+      constexpr int sl = decltype(SL_)::value;
+      mfma_slot(S1{}, SL_);
+      if constexpr (sl == 3) {  // tile t+1 has landed for every wave (only phase E's copies of tile t+2 may still be in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SC::CE) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      constexpr bool cp = loads && SC::o_copy(sl);
+      if constexpr (cp) {
+        if constexpr ((sl - SC::O0) % SC::PO == 0) copy_m0(integral_constant<int, SC::o_copy_index(sl)>{}, BUF_);
+        else copy_ld(integral_constant<int, SC::o_copy_index(sl)>{}, tl);
+      }
+      constexpr int nread = SC::o_read_index(sl, loads);
+      if constexpr (!cp && sl >= 4 && nread < NR) read1(NB{}, S0{}, integral_constant<int, nread>{});  // (past the last tile: dead data, unused)
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+  };
+
+  // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-step 0 fragments in registers
+  issue_tile(integral_constant<int, 0>{}, 0);
+  issue_tile(integral_constant<int, 1>{}, 1);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  W4_FENCE();
+  w4_for<NR>([&](auto R_) { read1(S0{}, S0{}, R_); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  W4_FENCE();
+
+  for (int t = 0; t < nk; t += 2) {  // nk is even (host): tile t from buffer 0, tile t+1 from buffer 1
+    phase_e(S0{}, t);
+    phase_o(S0{}, t);
+    phase_e(S1{}, t + 1);
+    phase_o(S1{}, t + 1);
+  }
+  // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // Staged epilogue (16-bit C): the accumulator layout gives a lane 4 consecutive n of one row, i.e. 32-byte pieces of 16 rows
+  // per store instruction.  Every wave instead packs its 128x128 quadrant into its own LDS slice ([128 rows][272 B]: 256 B of
+  // data + 16 B pad, conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 256
+  // contiguous bytes per row, 4 rows per instruction.  MH_EPI_ACCUM adds the old 16-bit values in fp32 on the way out.
+  __syncthreads();  // every wave is done with the operand tiles in LDS
+  char* stage = smem + wave * W4_CSTAGE;
+  const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
+  auto fill = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    w4_for<64>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epi_xform4<DT, EPI>(g, m, n, v);
+      const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+      const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(i * 16 * 272 + j * 32) : "memory");
+    });
+  };
+  switch (g.epi & ~MH_EPI_ACCUM) {
+    case 0: fill(integral_constant<int, 0>{}); break;
+    case MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_RESIDUAL>{}); break;
+    case MH_EPI_BIAS: fill(integral_constant<int, MH_EPI_BIAS>{}); break;
+    case MH_EPI_BIAS | MH_EPI_QUICK_GELU: fill(integral_constant<int, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{}); break;
+    case MH_EPI_BIAS | MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_BIAS | MH_EPI_RESIDUAL>{}); break;
+    default: break;  // excluded by the host
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
+  const int mrow = m0 + wm * 128 + (lane >> 4);
+  const int ncol = n0 + wn * 128 + (lane & 15) * 8;
+  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
+  const bool n_ok = ncol < g.N;
+  const bool accum = (g.epi & MH_EPI_ACCUM) != 0;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    u32x4 rv[8];
+    w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+    if (accum) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (n_ok && mrow + row < g.M) {
+          const uint4 old = *(const uint4*)(cp + (int64_t)row * g.ldc);
+          float a[8], o[8];
+          unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, a);
+          unpack8<DT>(old, o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += o[e];
+          *(uint4*)(cp + (int64_t)row * g.ldc) = pack8<DT>(a);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (n_ok && mrow + row < g.M) *(u32x4*)(cp + (int64_t)row * g.ldc) = rv[r];
+      }
+    }
+  }
+}
+
+template <int DT, bool AKS, bool BKS>
+int launch_w4(const GemmArgs& g, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_w4<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_w4<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
+  MH_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+// true when gemm_w4 can run this problem: whole K-tiles, 16-bit output through the staged epilogue (plain / bias / quick-GELU /
+// residual, optionally accumulating), 32-bit source offsets.  (The policy - where it is FASTER - lives in gemm.hip.)
+bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
+  const int e = g.epi & ~MH_EPI_ACCUM;
+  const bool known = e == 0 || e == MH_EPI_RESIDUAL || e == MH_EPI_BIAS || e == (MH_EPI_BIAS | MH_EPI_QUICK_GELU) || e == (MH_EPI_BIAS | MH_EPI_RESIDUAL);
+  if (!known || (g.epi & MH_EPI_OUT_F32) || !g.vec_ok || (g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
+  if (g.K % (2 * BK) != 0 || g.splits != 1 || g.rope_tab || g.sw_mode) return false;  // an even number of K-tiles (loop unrolled by buffer)
+  if (a_kstrided && (g.M % 8)) return false;
+  if (b_kstrided && (g.N % 8)) return false;
+  const int64_t lim = (1ll << 32) - (1 << 20);
+  const int64_t spanA = a_kstrided ? (int64_t)g.K * g.lda * 2 : (int64_t)g.M * g.lda * 2;
+  const int64_t spanB = b_kstrided ? (int64_t)g.K * g.ldb * 2 : (int64_t)g.N * g.ldb * 2;
+  return spanA < lim && spanB < lim;
+}
+
+int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream) {
+  const int key = (dt == MH_BF16 ? 0 : 4) | (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
+  switch (key) {
+    case 0: return launch_w4<MH_BF16, false, false>(g, stream);
+    case 1: return launch_w4<MH_BF16, false, true>(g, stream);
+    case 2: return launch_w4<MH_BF16, true, false>(g, stream);
+    case 3: return launch_w4<MH_BF16, true, true>(g, stream);
+    case 4: return launch_w4<MH_F16, false, false>(g, stream);
+    case 5: return launch_w4<MH_F16, false, true>(g, stream);
+    case 6: return launch_w4<MH_F16, true, false>(g, stream);
+    default: return launch_w4<MH_F16, true, true>(g, stream);
+  }
+}
+
+}  // namespace mhgemm

@@ -960,6 +960,11 @@ def gemm_persistent(on: bool):
     L.lib().mh_gemm_persistent(i32(1 if on else 0))
 
 
+def gemm_w4_policy(mask: int):
+    """A/B switch: operand layouts the auto selection sends to the 4-wave 256x256 GEMM (bit 0 TN, bit 1 NN, bit 2 NT; default 3)."""
+    L.lib().mh_gemm_w4_policy(i32(mask))
+
+
 def gemm_force_kernel(which: int):
     """0 = auto, 128 / 256 = force that tile size (tests, A/B benchmarks).  Other codes select the development arms and
     exist only in the dev library (tools/dev_arms/)."""

@@ -97,27 +97,30 @@ def test_general_mask_forward_backward_vs_oracle(kind, dtype):
 
 
 def test_right_padded_batch_is_bit_identical_through_the_general_path():
-    """The unpad / pad route on a right-padded batch = the lens-only fast path, bit for bit (same kernels on the same rows), forward
-    and backward; also with layer recompute (the packed copies are rebuilt in the backward)."""
+    """The unpad / pad route on a right-padded batch = the lens-only fast path: bit for bit in the forward (same kernels on the same
+    rows); in the backward up to one extra 16-bit rounding of dq / dk (the inverse RoPE runs on the un-packed rows as a separate
+    pass instead of in the attention kernels' fp32 epilogue); also with layer recompute (packed copies rebuilt in the backward)."""
     from oracle import cases as C
     from test_model_gpu import _build, _to_dev
 
     cfg, batch = C.get_case("tiny_padbatch")
     b = _to_dev(batch)
     model = _build(cfg, torch.bfloat16)
-    out0 = model(**b)
-    out0.loss.backward()
-    g0 = model.engine.arena.gflat.clone()
-    l0 = out0.logits.clone()
-    for save in (True, False):
-        for p in model.parameters():
-            p.grad = None
-        model.engine.force_unpad, model.engine.save_activations = True, save
-        out1 = model(**b)
-        out1.loss.backward()
-        valid = b["attention_mask"].bool()
-        assert torch.equal(out1.logits[valid], l0[valid]) and torch.equal(out1.loss, out0.loss)
-        assert torch.equal(model.engine.arena.gflat, g0)
+    valid = b["attention_mask"].bool()
+    for save in (True, False):  # (the tower's fc1 + quick-GELU is one fused launch without resident activations: compare like with like)
+        model.engine.save_activations = save
+        res = []
+        for general in (False, True):
+            for p in model.parameters():
+                p.grad = None
+            model.engine.force_unpad = general
+            out = model(**b)
+            out.loss.backward()
+            res.append((out.logits[valid].clone(), out.loss.clone(), model.engine.arena.gflat.clone()))
+        (l0, loss0, g0), (l1, loss1, g1) = res
+        assert torch.equal(l1, l0) and torch.equal(loss1, loss0)
+        cos = float((g1.float() * g0.float()).sum() / (g1.float().norm() * g0.float().norm()))
+        assert cos > 0.99995 and float((g1.float() - g0.float()).abs().max()) <= 0.02 * float(g0.float().abs().max()), cos
     model.engine.force_unpad = False
 
 

@@ -415,6 +415,65 @@ def test_gemm_kstrided_operands(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (304, 520, 256), (1000, 264, 384), (512, 768, 2048), (2064, 1288, 128)])
+def test_gemm_w4_all_layouts_and_epilogues(ops, dtype, M, N, K):
+    """csrc/gemm_w4.hip (4 waves x 128x128 outputs, mh_gemm_force_kernel(4)) in its NT / NN / TN / TT operand forms, edge tiles in both
+    dimensions, every staged epilogue incl. accumulate - against fp32 torch and against the 8-wave kernel (force 256); identity x
+    asymmetric operands catch a transposed fragment or C write (cdna guide rule 16)."""
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
+    ref = a.float() @ b.float().t()
+    at, bt = a.t().contiguous(), b.t().contiguous()
+    tol = 3 * EPS16[dtype]
+    try:
+        res = {}
+        for which in (4, 256):
+            ops.gemm_force_kernel(which)
+            r = res[which] = {}
+            r["nt"] = ops.gemm_nt(a, b)
+            r["nn"] = ops.gemm_nt(a, bt, b_t=True)
+            r["tn"] = ops.gemm_nt(at, bt, a_t=True, b_t=True)
+            r["tt"] = ops.gemm_nt(at, b, a_t=True)
+            r["bias"] = ops.gemm_nt(a, b, bias=bias)
+            r["gelu"] = ops.gemm_nt(a, b, bias=bias, act="quick_gelu")
+            r["resid"] = ops.gemm_nt(a, bt, b_t=True, resid=resid)
+            r["bias_resid"] = ops.gemm_nt(a, b, bias=bias, resid=resid)
+            acc = rnd(M, N, dtype=dtype, seed=4)
+            ops.gemm_nt(at, bt, a_t=True, b_t=True, out=acc, accum=True)
+            r["accum"] = acc
+        z = ref + bias.float()
+        want = dict(nt=ref, nn=ref, tn=ref, tt=ref, bias=z, gelu=z * torch.sigmoid(1.702 * z), resid=ref + resid.float(),
+                    bias_resid=z + resid.float(), accum=ref + rnd(M, N, dtype=dtype, seed=4).float())
+        for k, w in want.items():
+            assert relerr(res[4][k], w) < (4 * EPS16[dtype] if k != "nt" else tol), k
+            assert relerr(res[4][k], res[256][k].float()) < 2 * EPS16[dtype], (k, "vs the 8-wave kernel")
+        ops.gemm_force_kernel(4)
+        assert torch.equal(ops.gemm_nt(at, bt, a_t=True, b_t=True), res[4]["tn"])  # deterministic
+        if M == N == 256:
+            eye = torch.eye(256, dtype=dtype, device=dev())
+            asym = (torch.arange(256 * 256, device=dev()).reshape(256, 256) % 251).to(dtype)
+            assert torch.equal(ops.gemm_nt(eye, asym).float(), asym.float().t())                    # out[m, n] = asym[n, m]
+            assert torch.equal(ops.gemm_nt(eye, asym, b_t=True).float(), asym.float())              # B[k, n]
+            assert torch.equal(ops.gemm_nt(eye, asym, a_t=True, b_t=True).float(), asym.float())
+            assert torch.equal(ops.gemm_nt(asym, eye, a_t=True).float(), asym.float().t())          # A[k, m] -> out[m, n = k]
+    finally:
+        ops.gemm_force_kernel(0)
+
+
+def test_gemm_w4_at_the_weight_gradient_geometry(ops):
+    """The shapes the auto selection sends to gemm_w4: TN weight gradients over 32 768 tokens (q|k|v, gate|up with 86 tile columns,
+    down) - sampled tiles vs fp32, and the same launch through wgrad_tn."""
+    T = 32768
+    for No, Ki in ((12288, 4096), (4096, 11008)):
+        dy, x = rnd(T, No, dtype=torch.bfloat16, scale=0.05), rnd(T, Ki, dtype=torch.bfloat16, seed=1)
+        out = torch.empty(No, Ki, dtype=torch.bfloat16, device=dev())
+        ops.wgrad_tn(dy, x, out, accum=False)
+        for (r0, c0) in ((0, 0), (No - 256, Ki - 256), (1024 + 128, 2048 + 64)):
+            ref = dy[:, r0:r0 + 256].float().t() @ x[:, c0:c0 + 256].float()
+            assert relerr(out[r0:r0 + 256, c0:c0 + 256], ref) < 3 * EPS16[torch.bfloat16], (No, Ki, r0, c0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,No,Ki", [(27696, 1024, 1024), (27696, 3072, 1024), (1731, 1024, 256), (130, 512, 264), (64, 256, 256),
                                      (4100, 4096, 4096), (8192, 1024, 4096), (37, 256, 8)])
 def test_wgrad_tn_any_tokens_splitk(ops, dtype, T, No, Ki):

@@ -152,6 +152,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg-2 (S=613) row of the N=1 line's `extras`")
     ap.add_argument("--fp8-forward", action="store_true", help="with --fwd-only: decoder Linears on the scaled-fp8 MFMA (e4m3 operands, "
                     "per-row scales); NOT the headline configuration (dtype field says so)")
+    ap.add_argument("--fp32-residual", action="store_true", help="both towers' residual streams in fp32 (engine.fp32_residual): the "
+                    "closer-to-the-reference forward (DESIGN.md, parity table); NOT the headline configuration")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the model over gloo: exercises the launcher, GradSync, the "
                     "barrier / max-over-ranks timing and the JSON line without a GPU (tests/test_bench_cpu.py); the numbers mean nothing")
     ap.add_argument("--min-free-gb", type=float, default=10.0, help="N>1: if less HBM than this stays free next to RCCL's buffers after the "
@@ -226,7 +228,7 @@ def read_traffic(args):
     """HBM/fabric traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
     (tools/pmc_step_traffic.sh; PMC collection cannot run inside the timed process).  The committed summary is quoted only when
     it was taken on the kernel sources of THIS build (stamp) and for the default configuration."""
-    if args.config != "cfg3" or args.fwd_only or args.fp8_train or args.recompute or args.dry_run:
+    if args.config != "cfg3" or args.fwd_only or args.fp8_train or args.recompute or args.dry_run or args.fp32_residual:
         return None, None
     path = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
     try:
@@ -309,6 +311,7 @@ def main(argv=None):
         model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
         eng = model.engine
         eng.save_activations = not args.recompute
+        eng.fp32_residual = bool(args.fp32_residual)
         if args.fp8_forward:
             assert args.fwd_only, "--fp8-forward is forward-only"
             model.fp8_forward = True
@@ -452,7 +455,8 @@ def main(argv=None):
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("cpu-fp32 (dry run)" if dry else "fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
-                  "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else "bf16"),
+                  "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else
+                  "bf16 (fp32 residual streams)" if args.fp32_residual else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
                    "step": step_desc, "loss": round(loss_val, 4)},

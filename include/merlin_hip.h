@@ -170,6 +170,12 @@ int mh_rmsnorm_fwd_q8(const void* x, const void* w, void* y, void* q, float* sca
 int mh_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
 /* nn.LayerNorm (CLIP pre_layrnorm / layer_norm1 / layer_norm2, eps 1e-5). */
 int mh_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps, int dt, void* stream);
+/* fp32 RESIDUAL STREAM (opt-in, engine.fp32_residual): x is fp32 [rows, d], updated in place by the accumulating fp32 epilogue of the
+ * projections that feed it (mh_gemm with MH_EPI_OUT_F32 | MH_EPI_ACCUM [| MH_EPI_BIAS]).  y = RMSNorm(x; w) (b == NULL) or
+ * LayerNorm(x; w, b) in `dt` for the next GEMM; x16 (nullable) receives the 16-bit copy of x the backward keeps as the layer input.
+ * Removes every 16-bit rounding of HF's residual adds (LlamaDecoderLayer: `hidden_states = residual + hidden_states`) from the
+ * forward: BASELINE's "logits within 1e-3 rel fp16" at depth is limited by exactly those (profiles/r01_full_depth_rounding_attribution.txt). */
+int mh_norm_fwd_f32in(const float* x, const void* w, const void* b, void* y, void* x16, int rows, int d, float eps, int dt, void* stream);
 int mh_layernorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, float* db_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
 int mh_norm_bwd_partials(int rows);
 /* out[d] (dt) (+)= sum_r partial[r, d]  (finishes dw/db; also bias grads from mh_colsum) */

@@ -219,6 +219,7 @@ __device__ __forceinline__ void epi_dispatch(const GemmArgs& g, F&& body) {
       case MH_EPI_BIAS | MH_EPI_RESIDUAL: body(EpiStoreFast<DT, MH_EPI_BIAS | MH_EPI_RESIDUAL>{g}); return;
       case MH_EPI_OUT_F32: body(EpiStoreFast<DT, MH_EPI_OUT_F32>{g}); return;
       case MH_EPI_OUT_F32 | MH_EPI_ACCUM: body(EpiStoreFast<DT, MH_EPI_OUT_F32 | MH_EPI_ACCUM>{g}); return;
+      case MH_EPI_BIAS | MH_EPI_OUT_F32 | MH_EPI_ACCUM: body(EpiStoreFast<DT, MH_EPI_BIAS | MH_EPI_OUT_F32 | MH_EPI_ACCUM>{g}); return;
       case MH_EPI_ACCUM: body(EpiStoreFast<DT, MH_EPI_ACCUM>{g}); return;
       default: break;
     }

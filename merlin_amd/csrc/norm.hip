@@ -186,6 +186,58 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restric
   }
 }
 
+// fp32-RESIDUAL-STREAM forms (engine.fp32_residual; DESIGN.md "fp32 residual stream"): the stream x is fp32 [rows, d] and is
+// updated in place by the o / down (out_proj / fc2) projections' accumulating fp32 epilogue, so the only 16-bit roundings left on
+// the forward path are the GEMM operands.  This kernel is the stream's reader: y = norm(x) in 16 bits for the next GEMM, and
+// (x16 != NULL) the 16-bit copy of x that the backward keeps as the layer input.  Same arithmetic and summation order as
+// rmsnorm_fwd_k / layernorm_fwd_k; LN = true: LayerNorm (b != NULL).
+template <int DT, bool LN>
+__global__ __launch_bounds__(256) void norm_fwd_f32in_k(const float* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
+                                                        uint16_t* __restrict__ y, uint16_t* __restrict__ x16, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + (int64_t)row * d);
+  const uint4* wr = (const uint4*)w;
+  const uint4* br = (const uint4*)b;
+  uint4* yr = (uint4*)(y + (int64_t)row * d);
+  uint4* cr = x16 ? (uint4*)(x16 + (int64_t)row * d) : nullptr;
+  const int nch = d >> 3;
+  float mu = 0.f;
+  if constexpr (LN) {
+    float s = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+      const float4 a = xr[2 * c], e = xr[2 * c + 1];
+      s += a.x; s += a.y; s += a.z; s += a.w; s += e.x; s += e.y; s += e.z; s += e.w;
+    }
+    mu = wave_sum(s) / (float)d;
+  }
+  float ss = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const float4 a = xr[2 * c], e = xr[2 * c + 1];
+    const float f[8] = {a.x, a.y, a.z, a.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += (f[i] - mu) * (f[i] - mu);
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)d + eps);
+  for (int c = lane; c < nch; c += 64) {
+    const float4 a = xr[2 * c], e = xr[2 * c + 1];
+    float f[8] = {a.x, a.y, a.z, a.w, e.x, e.y, e.z, e.w}, g[8];
+    if (cr) cr[c] = pack8<DT>(f);
+    unpack8<DT>(wr[c], g);
+    if constexpr (LN) {
+      float h[8];
+      unpack8<DT>(br[c], h);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = (f[i] - mu) * r * g[i] + h[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+    }
+    yr[c] = pack8<DT>(f);
+  }
+}
+
 // Backward.  LN = false: RMSNorm, LN = true: LayerNorm.  NCH = chunks (of 8 elements) per lane.
 template <int DT, bool LN, int NCH>
 __global__ __launch_bounds__(256) void norm_bwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
@@ -453,6 +505,21 @@ extern "C" int mh_layernorm_fwd(const void* x, const void* w, const void* b, voi
     hipLaunchKernelGGL(layernorm_fwd_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)x,
                        (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, rows, d, eps);
   else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_norm_fwd_f32in(const float* x, const void* w, const void* b, void* y, void* x16, int rows, int d, float eps, int dt,
+                                 void* stream) {
+  if (!x || !w || !y || rows <= 0 || d <= 0 || (d & 7)) return MH_ERR_ARG;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (b && !aligned16(b)) || (x16 && !aligned16(x16))) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+#define NF32_GO(DT_, LN_)                                                                                                       \
+  hipLaunchKernelGGL((norm_fwd_f32in_k<DT_, LN_>), dim3(grid), dim3(256), 0, as_stream(stream), x, (const uint16_t*)w, (const uint16_t*)b, \
+                     (uint16_t*)y, (uint16_t*)x16, rows, d, eps)
+  if (dt == MH_BF16) { if (b) NF32_GO(MH_BF16, true); else NF32_GO(MH_BF16, false); }
+  else { if (b) NF32_GO(MH_F16, true); else NF32_GO(MH_F16, false); }
+#undef NF32_GO
   MH_LAUNCH_CHECK();
 }
 

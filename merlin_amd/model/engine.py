@@ -55,6 +55,10 @@ class HipEngine:
         self.strict_checks = True
         self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
         self.force_unpad = False  # tests: send right-padded masks through the general unpad / pad attention path as well
+        # opt-in: both towers' residual streams in fp32 (updated in place by the accumulating fp32 epilogue of the projections that feed
+        # them, read by mh_norm_fwd_f32in); GEMM operands, attention and every saved activation stay 16-bit.  Forward parity at depth:
+        # tests/test_model_gpu.py (full 7B) and profiles/r03_parity.txt; the backward is unchanged (16-bit copies of the layer inputs).
+        self.fp32_residual = False
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -315,6 +319,16 @@ class HipEngine:
         L = tower.layers_used
         train_tower = ctx is not None and ctx["train_tower"]
         xs, saves = [], []
+        if self.fp32_residual:
+            x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
+            for i in range(L):
+                x16, sv = self._vit_layer_fwd_r32(self.vit[i], x32, N, S, vc, keep=train_tower and self.save_activations)
+                if train_tower:
+                    xs.append(x16)
+                saves.append(sv)
+            x = O.convert(x32, torch.empty_like(x))  # hidden_states[select_layer] as the projector's 16-bit GEMM operand
+            del x32
+            L = 0
         for i in range(L):
             if train_tower:
                 xs.append(x)
@@ -426,6 +440,41 @@ class HipEngine:
         gu, act = O.gemm_swiglu_fwd(h2, W.wgu)  # gate|up projection; SwiGLU in the same launch's epilogue
         y = O.gemm_nt(act, W.wd, resid=x2)
         return y, ((h1, qkv, o, lse, x2, h2, gu, act, packed) if keep else None)
+
+    def _llama_layer_fwd_r32(self, W, x32, B, S, lens, keep, kv_out=None, unpad=None):
+        """_llama_layer_fwd on the fp32 residual stream: x32 [T, d] is updated IN PLACE; returns (x16 = the 16-bit copy of the layer
+        input for the backward, saved activations | None)."""
+        cfg = self.model.config
+        H, D = cfg.num_attention_heads, head_dim_of(cfg)
+        eps = cfg.rms_norm_eps
+        h1, x16 = O.norm_fwd_f32in(x32, W.ln1, eps, want_x16=True)
+        qkv = O.gemm_nt_rope(h1, W.wqkv, self.rope, S, H, D)
+        o, lse, packed = self._attn_fwd(qkv, B, S, H, D, lens, unpad, kv_out)
+        O.gemm_nt(o, W.wo, out=x32, accum=True)           # x += o Wo^T, fp32 read-modify-write in the GEMM epilogue
+        h2, x2_16 = O.norm_fwd_f32in(x32, W.ln2, eps, want_x16=keep)
+        gu, act = O.gemm_swiglu_fwd(h2, W.wgu)
+        O.gemm_nt(act, W.wd, out=x32, accum=True)         # x += act Wd^T
+        return x16, ((h1, qkv, o, lse, x2_16, h2, gu, act, packed) if keep else None)
+
+    def _vit_layer_fwd_r32(self, W, x32, N, S, vc, keep):
+        H = vc.num_attention_heads
+        vd = vc.hidden_size
+        D = vd // H
+        eps = vc.layer_norm_eps
+        h1, x16 = O.norm_fwd_f32in(x32, W.ln1w, eps, b=W.ln1b, want_x16=True)
+        qkv = O.gemm_nt(h1, W.wqkv, bias=W.bqkv)
+        q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
+        o, lse = O.attn_fwd2(q, k, v, N, S, H, D, causal=False)
+        O.gemm_nt(o, W.wo, bias=W.bo, out=x32, accum=True)
+        h2, x2_16 = O.norm_fwd_f32in(x32, W.ln2w, eps, b=W.ln2b, want_x16=keep)
+        if keep:
+            f1 = O.gemm_nt(h2, W.w1, bias=W.b1)
+            a = O.quick_gelu_fwd(f1)
+        else:
+            f1 = None
+            a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
+        O.gemm_nt(a, W.w2, bias=W.b2, out=x32, accum=True)
+        return x16, ((h1, qkv, o, lse, x2_16, h2, f1, a) if keep else None)
 
     # ---- attention under a key-padding mask (llama_flash_attn_monkey_patch.py:87-102) ---------------------------------------------
     # Right-padded batches (the collator's, collator.py:29-34) only need per-sample lengths: the kernels skip keys >= lens[b] and
@@ -742,7 +791,18 @@ class HipEngine:
             if want_grad:
                 raise RuntimeError("model.fp8_forward is the inference form (forward only); set model.fp8_training = True for the fp8 training step")
             F8 = getattr(self, "_fp8_fwd", None) or self.quantize_forward_weights()
-        for li, W in enumerate(self.llama):
+        r32 = self.fp32_residual
+        if r32:
+            if fp8:
+                raise RuntimeError("engine.fp32_residual is implemented for the 16-bit GEMM path (not with fp8_forward / fp8_training)")
+            x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
+            for li, W in enumerate(self.llama):
+                x16, sv = self._llama_layer_fwd_r32(W, x32, B, S, lens, keep=want_grad and self.save_activations,
+                                                    kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad)
+                if want_grad:
+                    xs.append(x16)
+                saves.append(sv)
+        for li, W in enumerate(self.llama if not r32 else ()):
             if fp8_train:
                 if kv_cache is not None:
                     raise RuntimeError("prefill runs the 16-bit or fp8-forward path")
@@ -761,8 +821,12 @@ class HipEngine:
             x, sv = self._llama_layer_fwd(W, x, B, S, lens, keep=want_grad and self.save_activations,
                                           kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad)
             saves.append(sv)
+        if r32:
+            hn, x = O.norm_fwd_f32in(x32, A.view("model.norm.weight"), cfg.rms_norm_eps, want_x16=want_grad)
+            del x32
+        else:
+            hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), cfg.rms_norm_eps)
         ctx.update(xs=xs, saves=saves, x_last=x if want_grad else None)
-        hn = O.rmsnorm_fwd(x, A.view("model.norm.weight"), cfg.rms_norm_eps)
         # ---- lm_head + shifted CE (llama_mmgpt.py:87-100) ----
         V = cfg.vocab_size
         Vpad = _ru(V, 64)

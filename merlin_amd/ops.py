@@ -833,6 +833,17 @@ def mask_lens(mask):
     return lens
 
 
+def norm_fwd_f32in(x32, w, eps, b=None, want_x16=False):
+    """Reader of the fp32 residual stream: (y, x16 | None) = (norm(x32) in w's 16-bit dtype, 16-bit copy of x32).  b = None: RMSNorm,
+    else LayerNorm.  include/merlin_hip.h: mh_norm_fwd_f32in."""
+    rows, d = x32.shape
+    assert x32.dtype == torch.float32 and x32.is_contiguous() and w.numel() == d
+    y = torch.empty(rows, d, dtype=w.dtype, device=x32.device)
+    x16 = torch.empty(rows, d, dtype=w.dtype, device=x32.device) if want_x16 else None
+    L.check(L.lib().mh_norm_fwd_f32in(p(x32), p(w), p(b), p(y), p(x16), i32(rows), i32(d), f32(eps), i32(dt_of(w)), _stream()), "mh_norm_fwd_f32in")
+    return y, x16
+
+
 def mask_unpad_index(mask):
     """bool/uint8 mask [B, S] -> (fwd int64 [B*S], inv int64 [B*S], count int32 [B]): the unpad / pad row tables of the key-padding
     attention branch (include/merlin_hip.h: mh_mask_unpad_index), consumed by gather_rows2d."""

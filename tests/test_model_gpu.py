@@ -112,8 +112,9 @@ def test_medium_forward_parity_vs_reference_golden(dtype):
     assert abs(float(out.loss) - float(g["loss"])) < tol["loss"] * abs(float(g["loss"]))
 
 
+@pytest.mark.parametrize("stream", ["16bit", "fp32"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype):
+def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     """BASELINE cfg 1/2 at FULL size (24-layer ViT-L/14-336 + 32-layer Llama-7B, S=613): logits slice,
     per-position logsumexp and loss of the HIP path vs the REAL reference's fp32 CPU outputs
     (tests/golden/full_cfg1.npz, generated by oracle/make_golden.py full).  Tolerance at full depth (32 layers
@@ -127,17 +128,66 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype):
     cfg, batch = C.get_case("full_cfg1")
     assert np.array_equal(g["input_ids"], batch["input_ids"].numpy())
     model = _build(cfg, dtype)
+    # stream = "fp32": engine.fp32_residual - both towers' residual streams in fp32 with the PRODUCTION GEMM / attention / norm kernels
+    # (VERDICT r2 #4); what is left is the 16-bit rounding of the GEMM operands (measured: profiles/r03_parity.txt)
+    model.engine.fp32_residual = stream == "fp32"
     with torch.no_grad():
         out = model(**_to_dev(batch))
     lg = out.logits.float()
     got = lg[:, ::16, :256].cpu().numpy()
     tl, tloss = (5e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1e-2)
+    if stream == "fp32":  # measured 2.1e-3 / 1.8e-2 (16-bit stream: 4.6e-3 / 3.5e-2)
+        tl = 2.6e-3 if dtype == torch.float16 else 2.2e-2
     err = np.abs(got - g["logits_slice"]).max() / float(g["logits_absmax"])
     assert err < tl, err
     lse = torch.logsumexp(lg, dim=-1).cpu().numpy()
     assert np.abs(lse - g["logits_lse"]).max() < 10 * tl
     assert abs(float(out.loss) - float(g["loss"])) < tloss * abs(float(g["loss"])), (float(out.loss), float(g["loss"]))
-    print(f"[full cfg1 {dtype}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
+    print(f"[full cfg1 {dtype} residual stream {stream}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["tiny_2img", "tiny_padbatch", "tiny_conv2"])
+def test_fp32_residual_stream_forward_backward_parity(name, dtype):
+    """engine.fp32_residual on the tiny fixtures: forward + backward vs the fp32 oracle (the backward runs on the 16-bit copies of the
+    layer inputs the stream's reader emits), with activations resident and with layer recompute; never worse than the 16-bit stream."""
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+
+    cfg, batch = C.get_case(name)
+    P = R.make_params(cfg, seed=0, requires_grad=True)
+    loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    valid = batch["attention_mask"].bool()
+    want = logits_ref.detach()[valid]
+    model = _build(cfg, dtype)
+    errs = {}
+    for r32, save in ((False, True), (True, True), (True, False)):
+        for p in model.parameters():
+            p.grad = None
+        model.engine.fp32_residual, model.engine.save_activations = r32, save
+        out = model(**_to_dev(batch))
+        out.loss.backward()
+        errs[(r32, save)] = float((out.logits.float().cpu()[valid] - want).abs().max() / want.abs().max())
+        if r32:
+            named = dict(model.named_parameters())
+            bad = []
+            for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.0.input_layernorm.weight",
+                      "lm_head.weight", "model.projector.projector.weight",
+                      "model.vision_tower.vision_tower.vision_model.encoder.layers.0.mlp.fc2.weight",
+                      "model.vision_tower.vision_tower.vision_model.encoder.layers.0.layer_norm1.weight"):
+                if named[k].grad is None:
+                    continue
+                gg, gr = named[k].grad.float().cpu().reshape(-1), P[k].grad.reshape(-1)
+                cos = float(gg @ gr / (gg.norm() * gr.norm() + 1e-30))
+                if cos < (0.999 if dtype == torch.float16 else 0.99):
+                    bad.append((k, cos))
+            assert not bad, bad
+            assert abs(float(out.loss) - float(loss_ref)) < (2e-3 if dtype == torch.float16 else 2e-2) * abs(float(loss_ref))
+    print(f"[fp32 residual {name} {dtype}] logits rel err 16-bit stream {errs[(False, True)]:.3e} -> fp32 stream {errs[(True, True)]:.3e}")
+    # (resident vs recompute differ in the tower only: fc1 + quick-GELU is one fused launch when nothing is kept)
+    assert errs[(True, True)] <= 1.05 * errs[(False, True)] + 1e-5 and abs(errs[(True, True)] - errs[(True, False)]) < (2e-4 if dtype == torch.float16 else 2e-3)
+    assert errs[(True, True)] < (1e-3 if dtype == torch.float16 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -156,6 +156,8 @@ def parse_args(argv=None):
                     "closer-to-the-reference forward (DESIGN.md, parity table); NOT the headline configuration")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the model over gloo: exercises the launcher, GradSync, the "
                     "barrier / max-over-ranks timing and the JSON line without a GPU (tests/test_bench_cpu.py); the numbers mean nothing")
+    ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the N>1 code path (RCCL process group of one rank, GradSync on its "
+                    "communication stream, per-rank gathers, headroom check) on the one GPU - a hardware check of the multi-GPU plumbing")
     ap.add_argument("--min-free-gb", type=float, default=10.0, help="N>1: if less HBM than this stays free next to RCCL's buffers after the "
                     "first warm-up step, every rank switches to layer recompute (reported as `recompute_fallback`)")
     return ap.parse_args(argv)
@@ -238,8 +240,9 @@ def read_traffic(args):
         return None, "no PMC summary for this round (profiles/r03_gemm_traffic.json)"
     if t.get("kernel_source_stamp") != kernel_source_stamp():
         return None, f"profiles/r03_gemm_traffic.json was taken on other kernel sources (stamp {t.get('kernel_source_stamp')}): not quoted"
-    return round(t["traffic_bytes_per_launch"] / 1e9, 3), "GB per launch (L2<->fabric incl. Infinity-Cache hits, PMC: profiles/r03_gemm_traffic.json; " \
-        f"algorithmic {t.get('algorithmic_bytes_per_launch', 0) / 1e9:.3f} GB per launch)"
+    return round(t["traffic_bytes_per_launch"] / 1e9, 3), "GB per GEMM kernel launch (L2<->fabric incl. Infinity-Cache hits, PMC: profiles/r03_gemm_traffic.json: " \
+        f"{t.get('traffic_bytes_per_step', 0) / 1e12:.2f} TB per step = {t.get('traffic_over_algorithmic', 0):.2f} x the algorithmic " \
+        f"{t.get('algorithmic_bytes_per_step', 0) / 1e12:.2f} TB; a bench `launch` below is one GEMM call = 1-3 kernel launches)"
 
 
 def main(argv=None):
@@ -264,15 +267,20 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         dev_sync = torch.cuda.synchronize
-    if world > 1:
+    dp = world > 1 or args.force_dp  # data-parallel plumbing active
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if dry:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     def all_max(x):
-        if world == 1:
+        if not dp:
             return float(x)
         t = torch.tensor([float(x)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -282,7 +290,7 @@ def main(argv=None):
         return -all_max(-float(x))
 
     def all_sum_int(x):
-        if world == 1:
+        if not dp:
             return int(x)
         t = torch.tensor([int(x)], device=dev, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -298,7 +306,7 @@ def main(argv=None):
         eng = _DryEngine(rank)
         B, S, n_img, n_tok = 2, 64, 0, 128
         workload = "DRY RUN: CPU stand-in over gloo (launcher / GradSync / timing protocol only)"
-        sync = GradSync(eng) if world > 1 else None
+        sync = GradSync(eng, force=args.force_dp) if dp else None
 
         def step():
             return eng.step(sync)
@@ -350,7 +358,7 @@ def main(argv=None):
         # max_grad_norm=1.0 clipping - all of it inside the timed step
         opt = FusedAdamW(eng, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
         it = [0]
-        sync = GradSync(eng) if world > 1 else None
+        sync = GradSync(eng, force=args.force_dp) if dp else None
 
         def train_step(db):
             out = model(**db)
@@ -373,7 +381,7 @@ def main(argv=None):
         if os.environ.get("MH_BENCH_PER_STEP"):  # warm-up profile (stderr): how many steps until the step time is flat
             dev_sync()
             print(f"[bench] warm-up step {wi}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
-        if wi == 0 and world > 1 and not dry and not args.fwd_only and eng.save_activations:
+        if wi == 0 and dp and not dry and not args.fwd_only and eng.save_activations:
             # RCCL has allocated its channels / staging buffers by now (the first all-reduces ran): with activations resident the
             # step peaks at ~251 of 288 GB on one GPU - if less than --min-free-gb stays free on ANY rank, all ranks recompute
             dev_sync()
@@ -384,7 +392,7 @@ def main(argv=None):
                 recompute_fallback = True
                 torch.cuda.empty_cache()
     dev_sync()
-    if world > 1:
+    if dp:
         dist.barrier()
     dev_sync()
     if O is not None:
@@ -398,7 +406,7 @@ def main(argv=None):
     for _ in range(args.steps):
         loss = step()
     dev_sync()
-    if world > 1:
+    if dp:
         dist.barrier()
     dev_sync()
     dt = time.perf_counter() - t0
@@ -418,26 +426,26 @@ def main(argv=None):
             for _ in range(2):
                 model(**dbatch)
             dev_sync()
-            if world > 1:
+            if dp:
                 dist.barrier()
             tf0 = time.perf_counter()
             for _ in range(nf):
                 model(**dbatch)
             dev_sync()
-            if world > 1:
+            if dp:
                 dist.barrier()
             fwd_dt = time.perf_counter() - tf0
         fwd_ms = all_max(fwd_dt) / nf * 1e3
     dt = all_max(dt)
     n_tok_all = all_sum_int(n_tok)
     per_rank = None
-    if world > 1:  # per-rank peak HBM and communication times, gathered on rank 0
+    if dp:  # per-rank peak HBM and communication times, gathered on rank 0
         mine = torch.tensor([peak_gb, comm["comm_ms_total"] / args.steps, comm["comm_ms_exposed"] / args.steps], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[round(float(v), 2) for v in t] for t in allr]
     if rank != 0:
-        if world > 1:
+        if dp:
             dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
@@ -469,11 +477,15 @@ def main(argv=None):
                      "avg_launch_ms": round(gms / max(n, 1), 4), "gemm_share_of_step": round(gms / (dt * 1e3), 3),
                      "algorithmic_gb_per_launch": round(prof_bytes.get("gemm_fp8" if fp8_dom else "gemm_nt", 0.0) / max(n, 1) / 1e9, 4)},
     }
-    if traffic and line["roofline"]["algorithmic_gb_per_launch"]:
-        line["roofline"]["traffic_over_algorithmic"] = round(traffic / line["roofline"]["algorithmic_gb_per_launch"], 2)
+    if traffic:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")) as f:
+                line["roofline"]["traffic_over_algorithmic"] = round(json.load(f)["traffic_over_algorithmic"], 2)
+        except Exception:
+            pass
     if dry:
         line["dry_run"] = True
-    if world > 1:
+    if dp:
         line["rccl_ranks"] = world
         line["comm_ms_total"] = round(max(r[1] for r in per_rank), 2)      # per step, slowest rank
         line["comm_ms_exposed"] = round(max(r[2] for r in per_rank), 2)    # per step: compute stream idle at the end of backward
@@ -524,7 +536,7 @@ def main(argv=None):
         except Exception as e:  # the baseline leg must never take the GPU number down
             line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -4,20 +4,27 @@ import glob, json, os, sqlite3, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+COLS = []
+
+
 def load(d):
+    """-> ({counter: sum over the GEMM dispatches}, {counter: number of DISTINCT dispatches}).  (A dispatch has one row per counter
+    and hardware instance - XCC / channel - so rows are summed and dispatches are counted by their id.)"""
     out = collections.defaultdict(float)
-    n = collections.Counter()
+    seen = collections.defaultdict(set)
     for db in glob.glob(d + "/**/*.db", recursive=True):
         c = sqlite3.connect(db)
         cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
+        COLS[:] = cols
         ix = {k: i for i, k in enumerate(cols)}
         name_col = "kernel_name" if "kernel_name" in ix else "name"
-        for r in c.execute("select * from counters_collection"):
+        id_col = next((k for k in ("dispatch_id", "kernel_dispatch_id", "correlation_id", "stack_id", "id") if k in ix), None)
+        for j, r in enumerate(c.execute("select * from counters_collection")):
             if "gemm_nt" not in str(r[ix[name_col]]) and "gemm_w4" not in str(r[ix[name_col]]):
                 continue
             out[r[ix["counter_name"]]] += float(r[ix["value"]])
-            n[r[ix["counter_name"]]] += 1
-    return out, n
+            seen[r[ix["counter_name"]]].add(r[ix[id_col]] if id_col else j)
+    return out, {k: len(v) for k, v in seen.items()}
 
 
 a, na = load(sys.argv[1]); b, nb = load(sys.argv[2]); c, nc = load(sys.argv[3]) if len(sys.argv) > 3 else ({}, {})
@@ -51,8 +58,10 @@ def algorithmic_bytes_per_step():
     return L * (fwd + dgrad + wgrad) + head + vit
 
 
-print(json.dumps({"kernel": "bf16 MFMA GEMM kernels (all launches of one cfg-3 training step)", "launches": launches,
-                  "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": algorithmic_bytes_per_step() / L,
+print(json.dumps({"kernel": "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)", "launches": launches,
+                  "steps_profiled": 2, "traffic_bytes_per_step": (read_bytes + write_bytes) / 2, "algorithmic_bytes_per_step": algorithmic_bytes_per_step(),
+                  "traffic_over_algorithmic": (read_bytes + write_bytes) / 2 / algorithmic_bytes_per_step(), "db_columns": COLS,
+                  "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": 2 * algorithmic_bytes_per_step() / L,
                   "fabric_read_bytes_per_launch": read_bytes / L, "fabric_write_bytes_per_launch": write_bytes / L,
                   "traffic_bytes_per_launch": (read_bytes + write_bytes) / L, "l2_hit_rate": hit / max(1.0, hit + miss),
                   "method": "rocprofv3 --pmc, separate passes (tools/pmc_step_traffic.sh); " + how + "; writes = 64*WRREQ_64B + 32*(WRREQ-WRREQ_64B); "

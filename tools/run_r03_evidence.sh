@@ -1,0 +1,17 @@
+# Round-3 evidence bundle (run on the GPU box from the repo root): rocprofv3 kernel stats of the default bench command, the PMC
+# traffic passes, the N>1 plumbing on one GPU, and the default bench line.  Outputs under gpurun_out/ (copy into profiles/).
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-v1}
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out
+rm -rf /tmp/kt
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-extras --no-forward-leg > /tmp/kt.log 2>&1
+f=$(find /tmp/kt -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $f > $R/gpurun_out/r03_step_cfg3_kernel_stats_$TAG.txt 2>&1 || ls -R /tmp/kt | head
+tail -1 /tmp/kt.log > $R/gpurun_out/r03_step_cfg3_bench_under_rocprof_$TAG.json
+bash $R/tools/pmc_step_traffic.sh r03_gemm_traffic.json > /dev/null 2>&1
+cd $R
+python bench.py --steps 4 --warmup 2 --force-dp --no-cpu-baseline --no-extras > gpurun_out/bench_r03_force_dp_$TAG.json 2> gpurun_out/bench_r03_force_dp_$TAG.err
+cp gpurun_out/r03_gemm_traffic.json profiles/r03_gemm_traffic.json
+python bench.py --steps 10 --warmup 3 > gpurun_out/bench_r03_default_$TAG.json 2> /dev/null
+tail -c 1500 gpurun_out/bench_r03_force_dp_$TAG.json; echo; head -30 gpurun_out/r03_step_cfg3_kernel_stats_$TAG.txt; cat gpurun_out/r03_gemm_traffic.json; python -c "
+import json; d=json.load(open('gpurun_out/bench_r03_default_$TAG.json')); print(d['ms_per_step'], d['value'], d['roofline'])"

@@ -193,7 +193,7 @@ struct RopeSpec {
   int sw_mode = 0, sw_ff = 0; void* sw_out = nullptr; const void* sw_in = nullptr; int64_t sw_ldo = 0, sw_ldi = 0;  // fused SwiGLU
 };
 // Shapes that go to gemm_w4 by default (see the call site).  g_w4_mask: bit 0 = TN (wgrad), bit 1 = NN (dgrad), bit 2 = NT (measured: 3 is best in the step).
-int g_w4_mask = 3;
+int g_w4_mask = 3 | 8;  // (bit 3: the fp8 NT products of the fp8 training step)
 extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
 static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi) {
   const int form = (a_ks && b_ks) ? 1 : (b_ks ? 2 : (a_ks ? 0 : 4));
@@ -358,6 +358,11 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   }
   g.tiles_m = (M + 255) / 256;
   g.tiles_n = fx.sw_mode == 1 ? (fx.sw_ff + 127) / 128 : (N + 255) / 256;
+  // 4-wave form (gemm_w4.hip) for exponent-free operands with a plain / residual / accumulating epilogue when the tiles fill the
+  // chip; mh_gemm_force_kernel(4) = wherever it can run, (256) = never; auto: mh_gemm_w4_policy bit 3
+  if (g_force_kernel != 256 && w4_f8_can_run(g) &&
+      (g_force_kernel == 4 || (g_force_kernel == 0 && (g_w4_mask & 8) && (int64_t)g.tiles_m * g.tiles_n >= 192 && K >= 4096)))
+    return launch_gemm_w4_f8(g, dt_out, as_stream(stream));
   return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
 }
 

@@ -235,6 +235,8 @@ int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0
 // gemm_w4.hip: 4 waves x 128x128 per wave, all operand layouts, staged 16-bit epilogue (plain / bias / gelu / residual / accumulate)
 bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided);
 int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
+bool w4_f8_can_run(const GemmArgs& g);  // fp8 operands (no block exponents), see gemm_w4.hip
+int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream);
 int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA
 int launch_gemm_nt_w8(const GemmArgs& g, int dt, hipStream_t stream);      // gemm256w8.hip (8 waves, dense asm stream)
 int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)

@@ -359,6 +359,218 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   }
 }
 
+// ---- fp8 operands (e4m3 bytes, per-row fp32 scales): the fp8 training step's NT products on the 4-wave structure ---------------------
+// Same tile, LDS image and copies as the 16-bit NT form with K counted in 2-byte units (a 128-byte LDS row = 128 k).  One
+// v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator tile and K-tile consumes BOTH 16-byte pieces of a fragment row (chunks kq and 4 + kq),
+// so a K-tile is 64 MFMAs of 32 cycles instead of 128 of 16, and the fragment double-buffering is by operand instead of by k-step:
+//   A fragments (8 x 8 registers) live in two sets that alternate per K-tile; B fragments are two half sets (j 0..3 / 4..7).
+//   phase E: 32 MFMAs with B[0..3] | read B[4..7] of tile t, lgkmcnt(0) + barrier B1 (buffer t&1 free), 10 copies of tile t+2
+//   phase O: 32 MFMAs with B[4..7] | vmcnt(10) + barrier B2 (tile t+1 landed), read A (other set) and B[0..3] of tile t+1, 6 copies
+// (up to three single-issue instructions behind a 32-cycle MFMA).  Hardware block scales stay 1.0; the per-row scales of both operands
+// are applied to the accumulators in the epilogue.  Weight block exponents are NOT handled here: the host sends only exponent-free
+// operands (weight gradients always; forward / dgrad weights while the quantiser's flag says every exponent is zero).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_f8_acc(f32x4_t& c, const i32x8& a, const i32x8& b, int scale) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(c) : "v"(a), "v"(b), "v"(scale));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = g.K / BK;
+  using std::integral_constant;
+
+  int voffA[8], voffB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = wave * 64 + j * 8 + (lane >> 3);
+    const int c = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    voffA[j] = (int)((int64_t)min(m0 + row, g.M - 1) * g.lda * 2 + c);
+    voffB[j] = (int)((int64_t)min(n0 + row, g.N - 1) * g.ldb * 2 + c);
+  }
+  auto make_rs = [](const void* p_) {
+    const uint64_t a_ = (uint64_t)(uintptr_t)p_;
+    return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)a_),
+                 __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_ >> 32) & 0xffffu)), -1, 0x00020000};
+  };
+  const i32x4 rsA = make_rs(g.A), rsB = make_rs(g.B);
+  const unsigned lds0 = lds_addr_of(smem);
+  const unsigned w_kc = lds0 + (unsigned)wave * 8192u;
+  auto copy_m0 = [&](auto C_, auto BUF_) {
+    constexpr int c = decltype(C_)::value, bu = decltype(BUF_)::value;
+    constexpr int imm = bu * W4_UNIT + (c >> 3) * W4_PART + (c & 7) * 1024;
+    const unsigned base_ = w_kc;
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(base_), "n"(imm) : "scc");
+  };
+  auto copy_ld = [&](auto C_, int t) {
+    constexpr int c = decltype(C_)::value;
+    const int vo = c < 8 ? voffA[c & 7] : voffB[c & 7];
+    const i32x4 rs = c < 8 ? rsA : rsB;
+    const unsigned soff = (unsigned)t * (unsigned)(BK * 2);
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
+  };
+
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, kq = lane >> 4;
+  const unsigned swz = (unsigned)((fr >> 1) & 7);
+  unsigned a_ad[2][2], b_ad[2][2];  // [buffer][16-byte piece: chunk kq / 4 + kq]
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      a_ad[b][h] = lds0 + (unsigned)b * W4_UNIT + (unsigned)(wm * 128 + fr) * 128 + (((4 * h + kq) ^ swz) << 4);
+      b_ad[b][h] = lds0 + (unsigned)b * W4_UNIT + W4_PART + (unsigned)(wn * 128 + fr) * 128 + (((4 * h + kq) ^ swz) << 4);
+    }
+  u32x4 fa[2][8][2];  // A fragments [set][row block i][piece]
+  u32x4 fb[8][2];     // B fragments [column block j][piece]
+  const int one = 127;  // E8M0 1.0 for both hardware block scales
+
+  // read instruction r of the A fragments of buffer BUF into set P (r = 2 i + piece); of B fragments j0..j0+3 (r = 2 (j - j0) + piece)
+  auto read_a = [&](auto BUF_, auto P_, auto R_) {
+    constexpr int bu = decltype(BUF_)::value, pset = decltype(P_)::value, r = decltype(R_)::value;
+    dsr128<(r >> 1) * 2048>(fa[pset][r >> 1][r & 1], a_ad[bu][r & 1]);
+  };
+  auto read_b = [&](auto BUF_, auto J0_, auto R_) {
+    constexpr int bu = decltype(BUF_)::value, j0 = decltype(J0_)::value, r = decltype(R_)::value;
+    dsr128<(j0 + (r >> 1)) * 2048>(fb[j0 + (r >> 1)][r & 1], b_ad[bu][r & 1]);
+  };
+  auto mfma8 = [&](auto P_, auto I_, auto J_) {
+    constexpr int pset = decltype(P_)::value, i = decltype(I_)::value, j = decltype(J_)::value;
+    const i32x8 a = {(int)fa[pset][i][0][0], (int)fa[pset][i][0][1], (int)fa[pset][i][0][2], (int)fa[pset][i][0][3],
+                     (int)fa[pset][i][1][0], (int)fa[pset][i][1][1], (int)fa[pset][i][1][2], (int)fa[pset][i][1][3]};
+    const i32x8 b = {(int)fb[j][0][0], (int)fb[j][0][1], (int)fb[j][0][2], (int)fb[j][0][3],
+                     (int)fb[j][1][0], (int)fb[j][1][1], (int)fb[j][1][2], (int)fb[j][1][3]};
+    // (operands swapped like the 16-bit kernels: the accumulator holds 4 consecutive n of one row m)
+    mfma_f8_acc(acc[i][j], b, a, one);
+  };
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
+  using I4 = integral_constant<int, 4>;
+  // K-tile t from buffer BUF with A set P (both = t & 1)
+  auto tile = [&](auto BUF_, int t) {
+    constexpr int bu = decltype(BUF_)::value;
+    using NB = integral_constant<int, 1 - bu>;
+    const int tl = min(t + 2, nk - 1);
+    // phase E
+    w4_for<32>([&](auto SL_) {
+      constexpr int sl = decltype(SL_)::value;
+      mfma8(BUF_, integral_constant<int, sl % 8>{}, integral_constant<int, sl / 8>{});
+      if constexpr (sl < 8) read_b(BUF_, I4{}, SL_);
+      if constexpr (sl == 10) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (sl >= 11 && sl <= 29 && ((sl - 11) & 1) == 0) {
+        copy_m0(integral_constant<int, (sl - 11) / 2>{}, BUF_);
+        copy_ld(integral_constant<int, (sl - 11) / 2>{}, tl);
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+    // phase O
+    w4_for<32>([&](auto SL_) {
+      constexpr int sl = decltype(SL_)::value;
+      mfma8(BUF_, integral_constant<int, sl % 8>{}, integral_constant<int, 4 + sl / 8>{});
+      if constexpr (sl == 1) {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (sl >= 2 && sl < 18) read_a(NB{}, NB{}, integral_constant<int, sl - 2>{});
+      if constexpr (sl >= 18 && sl < 26) read_b(NB{}, I0{}, integral_constant<int, sl - 18>{});
+      if constexpr (sl >= 3 && sl <= 23 && ((sl - 3) & 3) == 0) {
+        copy_m0(integral_constant<int, 10 + (sl - 3) / 4>{}, BUF_);
+        copy_ld(integral_constant<int, 10 + (sl - 3) / 4>{}, tl);
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+  };
+
+  // prologue: tiles 0 and 1 in flight, tile 0 landed, its A fragments (set 0) and B[0..3] in registers
+  w4_for<16>([&](auto C_) { copy_m0(C_, I0{}); copy_ld(C_, 0); });
+  w4_for<16>([&](auto C_) { copy_m0(C_, I1{}); copy_ld(C_, 1); });
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  W4_FENCE();
+  w4_for<16>([&](auto R_) { read_a(I0{}, I0{}, R_); });
+  w4_for<8>([&](auto R_) { read_b(I0{}, I0{}, R_); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  W4_FENCE();
+  for (int t = 0; t < nk; t += 2) {  // nk is even (host)
+    tile(I0{}, t);
+    tile(I1{}, t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // epilogue: C[m, n] = sc_m[m] * sc_n[n] * acc, then the staged 16-bit store of gemm_w4 (plain / bias / gelu / residual / accumulate)
+  __syncthreads();
+  char* stage = smem + wave * W4_CSTAGE;
+  const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
+  float sm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sm[i] = g.sc_m[min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1)];
+  auto fill = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    w4_for<64>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, j = tt / 8, i = tt % 8;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
+      const float4 sn = *(const float4*)(g.sc_n + n);
+      float v[4] = {acc[i][j][0] * (sm[i] * sn.x), acc[i][j][1] * (sm[i] * sn.y), acc[i][j][2] * (sm[i] * sn.z), acc[i][j][3] * (sm[i] * sn.w)};
+      epi_xform4<DT, EPI>(g, m, n, v);
+      const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+      const unsigned sw_ = st_w;
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(i * 16 * 272 + j * 32) : "memory");
+    });
+  };
+  switch (g.epi & ~MH_EPI_ACCUM) {
+    case 0: fill(integral_constant<int, 0>{}); break;
+    case MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_RESIDUAL>{}); break;
+    default: break;  // excluded by the host
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
+  const int mrow = m0 + wm * 128 + (lane >> 4);
+  const int ncol = n0 + wn * 128 + (lane & 15) * 8;
+  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
+  const bool n_ok = ncol < g.N;
+  const bool accum = (g.epi & MH_EPI_ACCUM) != 0;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    u32x4 rv[8];
+    w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = part * 32 + r * 4;
+      if (!(n_ok && mrow + row < g.M)) continue;
+      if (accum) {
+        const uint4 old = *(const uint4*)(cp + (int64_t)row * g.ldc);
+        float a[8], o[8];
+        unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, a);
+        unpack8<DT>(old, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += o[e];
+        *(uint4*)(cp + (int64_t)row * g.ldc) = pack8<DT>(a);
+      } else {
+        *(u32x4*)(cp + (int64_t)row * g.ldc) = rv[r];
+      }
+    }
+  }
+}
+
 template <int DT, bool AKS, bool BKS>
 int launch_w4(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
@@ -385,6 +597,28 @@ bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
   const int64_t spanA = a_kstrided ? (int64_t)g.K * g.lda * 2 : (int64_t)g.M * g.lda * 2;
   const int64_t spanB = b_kstrided ? (int64_t)g.K * g.ldb * 2 : (int64_t)g.N * g.ldb * 2;
   return spanA < lim && spanB < lim;
+}
+
+// fp8 form: both operands K-contiguous bytes (g.K, lda, ldb in 2-byte units), no weight block exponents, plain / residual /
+// accumulating 16-bit epilogue, an even number of 128-byte K-tiles
+bool w4_f8_can_run(const GemmArgs& g) {
+  const int e = g.epi & ~MH_EPI_ACCUM;
+  if (!(e == 0 || e == MH_EPI_RESIDUAL) || (g.epi & MH_EPI_OUT_F32) || !g.vec_ok || (g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
+  if (g.K % (2 * BK) != 0 || g.splits != 1 || g.rope_tab || g.sw_mode || g.sc_e) return false;
+  if ((((uintptr_t)g.sc_n) & 15u) != 0 || (g.N % 4)) return false;
+  const int64_t lim = (1ll << 32) - (1 << 20);
+  return (int64_t)g.M * g.lda * 2 < lim && (int64_t)g.N * g.ldb * 2 < lim;
+}
+int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_w4_f8<MH_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    hipFuncSetAttribute((const void*)gemm_w4_f8<MH_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    attr_set = true;
+  }
+  if (dt == MH_BF16) hipLaunchKernelGGL((gemm_w4_f8<MH_BF16>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
+  else hipLaunchKernelGGL((gemm_w4_f8<MH_F16>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
+  MH_LAUNCH_CHECK();
 }
 
 int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream) {

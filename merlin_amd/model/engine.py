@@ -526,8 +526,8 @@ class HipEngine:
         """fp8 (e4m3, one scale per output channel) copies of the decoder's Linear weights for the fp8 FORWARD (inference /
         prefill form of BASELINE cfg 5's fp8 MFMA weight path).  Re-run after the weights change."""
         self.ensure_arena()
-        self._fp8_fwd = [dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), wgu=O.quant_fp8_rows_e4(W.wgu),
-                              wd=O.quant_fp8_rows_e4(W.wd)) for W in self.llama]
+        self._fp8_fwd = self._drop_zero_exponents([dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), wgu=O.quant_fp8_rows_e4(W.wgu),
+                                                        wd=O.quant_fp8_rows_e4(W.wd)) for W in self.llama])
         return self._fp8_fwd
 
     def _llama_layer_fwd_fp8(self, W, Q, x, B, S, lens, kv_out=None, unpad=None):
@@ -559,8 +559,23 @@ class HipEngine:
                 out.append(dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), wgu=O.quant_fp8_rows_e4(W.wgu), wd=O.quant_fp8_rows_e4(W.wd),
                                 wqkvT=O.quant_fp8_rows_t_e4(W.wqkv), woT=O.quant_fp8_rows_t_e4(W.wo), wguT=O.quant_fp8_rows_t_e4(W.wgu),
                                 wdT=O.quant_fp8_rows_t_e4(W.wd)))
-            return out
+            return self._drop_zero_exponents(out)
         return self._derive("fp8_train_weights", make)[li]
+
+    @staticmethod
+    def _drop_zero_exponents(layers):
+        """The quantiser leaves a device flag per weight: "some 128-block exponent is non-zero".  Read all of them back ONCE per weight
+        version (one host sync per optimizer step) and drop the exponent image of every weight whose blocks all sit within a factor 2
+        of their row maximum (i.i.d.-like weights: all of them) - such operands may take the 4-wave fp8 GEMM (csrc/gemm_w4.hip), which
+        applies per-row scales only; the others keep the image and the 8-wave kernel's block-scaled loop."""
+        trip = [(d, k) for d in layers for k, v in d.items() if len(v) > 2 and v[2] is not None]
+        if not trip:
+            return layers
+        flags = torch.stack([d[k][2][:4].view(torch.int32) for d, k in trip]).view(-1).cpu()
+        for (d, k), f in zip(trip, flags.tolist()):
+            if f == 0:
+                d[k] = d[k][:2]
+        return layers
 
     def _llama_layer_fwd_fp8_train(self, W, li, x, B, S, lens, keep, unpad=None):
         cfg = self.model.config

@@ -119,6 +119,36 @@ def test_rmsnorm_with_fused_row_quantisation_is_bit_identical(dtype, rows, d):
     assert torch.equal(y, y0) and torch.equal(s, s0) and torch.equal(q, q0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (520, 1000, 512), (2048, 768, 4096), (304, 264, 1280)])
+def test_fp8_gemm_4wave_form_matches_the_8wave_kernel(dtype, M, N, K):
+    """csrc/gemm_w4.hip gemm_w4_f8 (mh_gemm_force_kernel(4)): the fp8 NT product on the 4-wave structure - exact against the fp32 product of
+    the dequantised operands like the 8-wave kernel (same bytes, same per-K-tile MFMA, fp32 accumulation in the same K order), with the
+    plain, residual and accumulating epilogues and edge tiles."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 2).to(dtype)
+    b = (torch.randn(N, K, generator=g, device="cuda") * 0.5).to(dtype)
+    resid = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+    a8, b8 = O.quant_fp8_rows(a), O.quant_fp8_rows(b)
+    ref = (a8[0].view(torch.float8_e4m3fn).float() * a8[1][:, None]) @ (b8[0].view(torch.float8_e4m3fn).float() * b8[1][:, None]).t()
+    try:
+        out = {}
+        for which in (4, 256):
+            O.gemm_force_kernel(which)
+            acc = resid.clone()
+            O.gemm_fp8(a8, b8, out=acc, accum=True)
+            out[which] = (O.gemm_fp8(a8, b8, out_dtype=dtype), O.gemm_fp8(a8, b8, out_dtype=dtype, resid=resid), acc)
+        for k, want in enumerate((ref, ref + resid.float(), ref + resid.float())):
+            assert _relerr(out[4][k], want) < 3 * EPS[dtype], k
+            assert _relerr(out[4][k], out[256][k]) < 2 * EPS[dtype], (k, "vs the 8-wave kernel")
+        O.gemm_force_kernel(4)
+        assert torch.equal(O.gemm_fp8(a8, b8, out_dtype=dtype), out[4][0])
+    finally:
+        O.gemm_force_kernel(0)
+
+
 def _deq_e4(q, s, ex, n_rows, K):
     """dequantise (q [N, K] e4m3 bytes, s [N], exponent image) -> fp32 [N, K]"""
     nkb = K // 128

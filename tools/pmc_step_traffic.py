@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 COLS = []
+PER = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> counter -> sum
 
 
 def load(d):
@@ -12,6 +13,7 @@ def load(d):
     and hardware instance - XCC / channel - so rows are summed and dispatches are counted by their id.)"""
     out = collections.defaultdict(float)
     seen = collections.defaultdict(set)
+    per = PER
     for db in glob.glob(d + "/**/*.db", recursive=True):
         c = sqlite3.connect(db)
         cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
@@ -24,6 +26,8 @@ def load(d):
                 continue
             out[r[ix["counter_name"]]] += float(r[ix["value"]])
             seen[r[ix["counter_name"]]].add(r[ix[id_col]] if id_col else j)
+            kn = str(r[ix[name_col]]).replace("mhgemm::", "").replace("(anonymous namespace)::", "").split("(")[0]
+            per[kn][r[ix["counter_name"]]] += float(r[ix["value"]])
     return out, {k: len(v) for k, v in seen.items()}
 
 
@@ -58,7 +62,18 @@ def algorithmic_bytes_per_step():
     return L * (fwd + dgrad + wgrad) + head + vit
 
 
-print(json.dumps({"kernel": "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)", "launches": launches,
+def _kernel_rows():
+    rows = {}
+    for kn, c in PER.items():
+        rd = 32 * c.get("TCC_EA0_RDREQ_32B_sum", 0.0) + 64 * c.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 128 * c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        wrq, wr64q = c.get("TCC_EA0_WRREQ_sum", 0.0), c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        h, m = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
+        rows[kn] = {"fabric_read_gb_per_step": round(rd / 2 / 1e9, 1), "fabric_write_gb_per_step": round((64 * wr64q + 32 * (wrq - wr64q)) / 2 / 1e9, 1),
+                    "l2_hit_rate": round(h / max(1.0, h + m), 4)}
+    return rows
+
+
+print(json.dumps({"per_kernel": _kernel_rows(), "kernel": "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)", "launches": launches,
                   "steps_profiled": 2, "traffic_bytes_per_step": (read_bytes + write_bytes) / 2, "algorithmic_bytes_per_step": algorithmic_bytes_per_step(),
                   "traffic_over_algorithmic": (read_bytes + write_bytes) / 2 / algorithmic_bytes_per_step(), "db_columns": COLS,
                   "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": 2 * algorithmic_bytes_per_step() / L,

@@ -147,7 +147,7 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
 void mh_gemm_force_kernel(int which);
 /* Operand layouts the auto selection gives to the 4-wave kernel when K >= 4096 and the epilogue is a plain (or accumulating)
  * 16-bit store: bit 0 = TN (weight gradients: both operands K-strided), bit 1 = NN (dgrad), bit 2 = NT (forward; also with a
- * residual).  Default 3 (measured: profiles/r03_gemm_w4_ab.txt). */
+ * residual), bit 3 = the fp8 training step's exponent-free NT products (gemm_w4_f8).  Default 11 (measured: profiles/r03_gemm_w4_ab.txt). */
 void mh_gemm_w4_policy(int mask);
 /* 256x256-tile kernels: 1 (default) = persistent launch, one block per CU looping over the output tiles with the next tile's
  * first K-tile fetched under the epilogue; 0 = one block per tile (A-B benchmarks). */

@@ -972,7 +972,7 @@ def gemm_persistent(on: bool):
 
 
 def gemm_w4_policy(mask: int):
-    """A/B switch: operand layouts the auto selection sends to the 4-wave 256x256 GEMM (bit 0 TN, bit 1 NN, bit 2 NT; default 3)."""
+    """A/B switch: operand layouts the auto selection sends to the 4-wave 256x256 GEMM (bit 0 TN, bit 1 NN, bit 2 NT, bit 3 fp8 NT; default 11)."""
     L.lib().mh_gemm_w4_policy(i32(mask))
 
 

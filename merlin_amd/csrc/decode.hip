@@ -19,6 +19,21 @@
 // A decode step of a layer is 6 launches; each costs ~4 us of fixed time on top of its streaming, which is why the neighbours are folded in.
 #include "mh_common.h"
 
+// Weights and KV-cache rows are read ONCE per decode step by ONE CU: non-temporal loads (MI355X_MICROARCH.md "nt-weights": issued -> landed
+// -18 %, a decode layer 5-10 % faster) keep them from displacing the small activation vectors every block re-reads.  A/B: -DMH_DECODE_NT=0.
+#ifndef MH_DECODE_NT
+#define MH_DECODE_NT 1
+#endif
+typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+#if MH_DECODE_NT
+  const du32x4 v = __builtin_nontemporal_load((const du32x4*)p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *(const uint4*)p;
+#endif
+}
+
 namespace {
 
 // packed dot product of two 16-bit pairs with fp32 accumulate (v_dot2c_f32_bf16 / v_dot2c_f32_f16): no unpacking, half
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void gemv_k(const uint16_t* __restrict__ x, in
         for (int h2 = 0; h2 < NSTEP; ++h2)
 #pragma unroll
           for (int r = 0; r < ROWS; ++r)
-            wv[h2][r] = (k0 + h2 * 512 < klen) ? *(const uint4*)(wrow[r] + kc + k0 + h2 * 512) : make_uint4(0, 0, 0, 0);
+            wv[h2][r] = (k0 + h2 * 512 < klen) ? ld_stream16(wrow[r] + kc + k0 + h2 * 512) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int h2 = 0; h2 < NSTEP; ++h2) {
           const int kk = k0 + h2 * 512;
@@ -260,9 +275,9 @@ __global__ __launch_bounds__(256) void gemv_ks_k(const uint16_t* __restrict__ x,
     uint4 wv[2][ROWS];
     const bool two = k0 + 512 < ke;
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) wv[0][r] = *(const uint4*)(wrow[r] + k0);
+    for (int r = 0; r < ROWS; ++r) wv[0][r] = ld_stream16(wrow[r] + k0);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) wv[1][r] = two ? *(const uint4*)(wrow[r] + k0 + 512) : make_uint4(0, 0, 0, 0);
+    for (int r = 0; r < ROWS; ++r) wv[1][r] = two ? ld_stream16(wrow[r] + k0 + 512) : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       if (h2 == 1 && !two) break;
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(256) void gemv_fp8w_k(const uint16_t* __restrict__ 
         float s[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-          qv[r] = *(const uint4*)(qrow[r] + kc + k0);
+          qv[r] = ld_stream16(qrow[r] + kc + k0);
           s[r] = srow[r][(kc + k0) >> 7];
         }
         float p[ROWS][MM];
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(256) void gemv_fp8w_ks_k(const uint16_t* __restrict
     float s[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      qv[r] = *(const uint4*)(qrow[r] + k0);
+      qv[r] = ld_stream16(qrow[r] + k0);
       s[r] = srow[r][k0 >> 7];
     }
     float p[ROWS][MM];
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_k(const uint16_t* __restric
       const bool ok = k < K;
 #pragma unroll
       for (int g = 0; g < RG; ++g) {
-        wv[g][u] = ok ? *(const uint4*)(wr[g] + (int64_t)k * ES) : make_uint4(0, 0, 0, 0);
+        wv[g][u] = ok ? ld_stream16(wr[g] + (int64_t)k * ES) : make_uint4(0, 0, 0, 0);
         if constexpr (FP8W) sv[g][u] = ok ? sr[g][k >> 7] : 0.f;
       }
       xv[u][0] = (ok && arow) ? *(const uint4*)(xr + k) : make_uint4(0, 0, 0, 0);
@@ -818,7 +833,7 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * KPI + ksub;
-      kraw[u] = (j < len) ? *(const uint4*)(kc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + kpart * 8) : make_uint4(0, 0, 0, 0);
+      kraw[u] = (j < len) ? ld_stream16(kc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + kpart * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -865,7 +880,7 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * G;
       const bool ok = j < len;
-      vraw[u] = ok ? *(const uint4*)(vc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + c * 8) : make_uint4(0, 0, 0, 0);
+      vraw[u] = ok ? ld_stream16(vc + ((int64_t)b * Smax + j) * HD + (int64_t)h * D + c * 8) : make_uint4(0, 0, 0, 0);
       pj[u] = ok ? sc[j] : 0.f;
     }
 #pragma unroll

@@ -312,16 +312,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
       const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
       const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
       asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(i * 16 * 272 + j * 32) : "memory");
+      if constexpr (tt % 8 == 7) W4_FENCE();  // (keeps hipcc from reading all 256 accumulators into VGPRs at once)
     });
   };
-  switch (g.epi & ~MH_EPI_ACCUM) {
-    case 0: fill(integral_constant<int, 0>{}); break;
-    case MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_RESIDUAL>{}); break;
-    case MH_EPI_BIAS: fill(integral_constant<int, MH_EPI_BIAS>{}); break;
-    case MH_EPI_BIAS | MH_EPI_QUICK_GELU: fill(integral_constant<int, MH_EPI_BIAS | MH_EPI_QUICK_GELU>{}); break;
-    case MH_EPI_BIAS | MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_BIAS | MH_EPI_RESIDUAL>{}); break;
-    default: break;  // excluded by the host
-  }
+  // (two variants only: every further instantiation of this 64-tile block behind a switch makes hipcc spill more of the accumulators
+  // around the merge - the bias / quick-GELU epilogues belong to the CLIP tower's K = 1024 GEMMs, which stay on the 8-wave kernel anyway)
+  if ((g.epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL) fill(integral_constant<int, MH_EPI_RESIDUAL>{});
+  else fill(integral_constant<int, 0>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
   const int mrow = m0 + wm * 128 + (lane >> 4);
@@ -588,7 +585,7 @@ int launch_w4(const GemmArgs& g, hipStream_t stream) {
 // residual, optionally accumulating), 32-bit source offsets.  (The policy - where it is FASTER - lives in gemm.hip.)
 bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
   const int e = g.epi & ~MH_EPI_ACCUM;
-  const bool known = e == 0 || e == MH_EPI_RESIDUAL || e == MH_EPI_BIAS || e == (MH_EPI_BIAS | MH_EPI_QUICK_GELU) || e == (MH_EPI_BIAS | MH_EPI_RESIDUAL);
+  const bool known = e == 0 || e == MH_EPI_RESIDUAL;
   if (!known || (g.epi & MH_EPI_OUT_F32) || !g.vec_ok || (g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
   if (g.K % (2 * BK) != 0 || g.splits != 1 || g.rope_tab || g.sw_mode) return false;  // an even number of K-tiles (loop unrolled by buffer)
   if (a_kstrided && (g.M % 8)) return false;

@@ -75,7 +75,7 @@ def _kernel_rows():
 
 print(json.dumps({"per_kernel": _kernel_rows(), "kernel": "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)", "launches": launches,
                   "steps_profiled": 2, "traffic_bytes_per_step": (read_bytes + write_bytes) / 2, "algorithmic_bytes_per_step": algorithmic_bytes_per_step(),
-                  "traffic_over_algorithmic": (read_bytes + write_bytes) / 2 / algorithmic_bytes_per_step(), "db_columns": COLS,
+                  "traffic_over_algorithmic": (read_bytes + write_bytes) / 2 / algorithmic_bytes_per_step(),
                   "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": 2 * algorithmic_bytes_per_step() / L,
                   "fabric_read_bytes_per_launch": read_bytes / L, "fabric_write_bytes_per_launch": write_bytes / L,
                   "traffic_bytes_per_launch": (read_bytes + write_bytes) / L, "l2_hit_rate": hit / max(1.0, hit + miss),

@@ -1,0 +1,17 @@
+"""Tiny driver for PMC runs of the PRODUCT attention kernels: forward + backward at the cfg-3 geometry, causal and non-causal."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from merlin_amd import ops as O
+dev = torch.device("cuda:0")
+B, S, H, D = 8, 4096, 32, 128
+causal = (sys.argv[1] if len(sys.argv) > 1 else "1") == "1"
+qkv = (torch.randn(B * S, 3 * H * D, device=dev) * 0.5).bfloat16()
+q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
+do = torch.randn(B * S, H * D, device=dev).bfloat16()
+dqkv = torch.empty_like(qkv)
+o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=causal)
+for _ in range(2):
+    O.attn_fwd2(q, k, v, B, S, H, D, causal=causal, out=o, lse=lse)
+    O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, dq=dqkv[:, :H * D], dk=dqkv[:, H * D:2 * H * D], dv=dqkv[:, 2 * H * D:])
+torch.cuda.synchronize()

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
       constexpr int n = decltype(I)::value;
       lds_read128<(n / KSTEPS) * 32 * RB>(wk[n % WK], ak[n % KSTEPS]);
     });
+    prio_mfma(true);
     static_for<NKF>([&](auto I) {
       constexpr int n = decltype(I)::value;
       constexpr int left = NKF - 1 - n;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
       if constexpr (n + WK < NKF) lds_read128<((n + WK) / KSTEPS) * 32 * RB>(wk[n % WK], ak[(n + WK) % KSTEPS]);
     });
 
+    prio_mfma(false);
     // ---- first V^T fragments go out now; their latency hides under the softmax ----
     u32x2_t wv[8];  // window of 4 fragments = 8 transpose-reads
     static_for<4>([&](auto I) {
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
     }
 
     // ---- O^T += V^T P^T: fragment f = (d-block f/4, k-step f%4), rolling window of 4 fragments ----
+    prio_mfma(true);
     static_for<NVF>([&](auto I) {
       constexpr int f = decltype(I)::value;
       constexpr int left = NVF - 1 - f;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
         lds_read64_tr<((g % 4) * 16 + 8) * RB>(wv[2 * (f % 4) + 1], av[2 * (g / 4) + 1]);
       }
     });
+    prio_mfma(false);
   };
   // tiles [0, n_full) need no masking for any wave of this block
   const int n_full = min(ntiles, CAUSAL ? min(q0, len) / 64 : len / 64);

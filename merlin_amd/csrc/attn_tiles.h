@@ -20,7 +20,19 @@
 
 #include "mh_common.h"
 
+#ifndef MH_ATTN_SETPRIO
+#define MH_ATTN_SETPRIO 1  // raise the wave's priority over its MFMA clusters in the two-waves-per-SIMD kernels (A/B: -DMH_ATTN_SETPRIO=0)
+#endif
+
 namespace mhattn {
+
+// cdna guide T5: in the kernels that run two unsynchronised waves per SIMD (forward, dQ) the wave inside an MFMA cluster should win
+// issue arbitration over its partner's softmax / address arithmetic, so the matrix pipe stays fed
+__device__ __forceinline__ void prio_mfma(bool on) {
+#if MH_ATTN_SETPRIO
+  if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 

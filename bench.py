@@ -230,15 +230,15 @@ class _DryEngine:
 
 
 def kernel_source_stamp():
-    """sha256 over the HIP sources: profiles/*traffic*.json files carry it, and a PMC summary taken on other kernels is not quoted."""
+    """sha256 over the GEMM kernel sources (the kernels `roofline.traffic` is about): profiles/*traffic*.json files carry it, and a PMC
+    summary taken on other GEMM kernels is not quoted."""
     import hashlib
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "merlin_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+    for f in ("gemm.hip", "gemm256.hip", "gemm_w4.hip", "gemm_common.h", "mh_common.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 

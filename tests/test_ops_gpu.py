@@ -970,3 +970,40 @@ def test_gemm_fp8_fused_rope_and_swiglu_match_unfused(ops, dtype):
     gu_ref = ops.gemm_fp8(qx, qg, out_dtype=dtype)
     gu, act = ops.gemm_fp8_swiglu_fwd(qx, qg, out_dtype=dtype)
     assert torch.equal(gu, gu_ref) and torch.equal(act, ops.swiglu_fwd(gu_ref))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,causal,ragged", [(2, 256, 2, True, False), (1, 1000, 3, True, False), (2, 613, 2, True, True), (1, 1536, 2, False, False),
+                                                  (3, 700, 1, False, True), (1, 4096, 2, True, False), (2, 2432, 1, True, True)])
+def test_attention_forward_wide_form_matches(ops, dtype, B, S, H, causal, ragged):
+    """csrc/attn_fwd3.hip (mh_attn_fwd_wide(1): one wave per SIMD, 64 queries per wave, 256-query blocks) against the 128-query form
+    (itself held to a chunked fp32 reference elsewhere in this file) and against fp32 torch on one head: ragged lengths, sequence
+    lengths that are not a multiple of the 256-row block, causal and not, padded rows zero."""
+    D = 128
+    g = torch.Generator(device="cuda").manual_seed(S + H)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g, device="cuda") * 0.7).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    lens = None
+    if ragged:
+        lens = torch.tensor([max(1, S - 37 * (b + 1) - (b * 211) % S // 3) for b in range(B)], dtype=torch.int32, device="cuda")
+    try:
+        ops.attn_fwd_wide(False)
+        o0, l0 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+        ops.attn_fwd_wide(True)
+        o1, l1 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+        o2, _ = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+    finally:
+        ops.attn_fwd_wide(False)
+    assert torch.equal(o1, o2)  # deterministic
+    assert relerr(o1, o0.float()) < 2 * EPS16[dtype], relerr(o1, o0.float())
+    assert float((l1[:, :, :S] - l0[:, :, :S]).abs().max()) < 1e-3
+    # fp32 torch on batch 0, head 0
+    n = int(lens[0]) if lens is not None else S
+    qf, kf, vf = (t[:n, :D].float() for t in (q, k, v))
+    sc = qf @ kf.t() / D ** 0.5
+    if causal:
+        sc = sc.masked_fill(torch.ones(n, n, device="cuda", dtype=torch.bool).triu(1), float("-inf"))
+    ref = torch.softmax(sc, -1) @ vf
+    assert relerr(o1[:n, :D], ref) < 4 * EPS16[dtype]
+    if n < S:
+        assert float(o1[n:S, :D].abs().max()) == 0.0

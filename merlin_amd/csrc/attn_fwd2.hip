@@ -254,11 +254,11 @@ int launch_fwd2(const Fwd2Args& a, hipStream_t st) {
 }  // namespace mhattn
 
 namespace mhattn {
-int launch_attn_fwd_wide(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
+int launch_attn_fwd_pingpong(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
                          const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st);  // attn_fwd3.hip
-int g_attn_fwd_wide = 0;
+int g_attn_fwd_pingpong = 0;
 }  // namespace mhattn
-extern "C" void mh_attn_fwd_wide(int on) { mhattn::g_attn_fwd_wide = on ? 1 : 0; }
+extern "C" void mh_attn_fwd_pingpong(int on) { mhattn::g_attn_fwd_pingpong = on ? 1 : 0; }
 
 extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                             int64_t ldo, float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt,
@@ -266,8 +266,8 @@ extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t l
   using namespace mhattn;
   if (!q || !k || !v || !o || !lse || B <= 0 || S <= 0 || H <= 0) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v)) return MH_ERR_ARG;
-  if (g_attn_fwd_wide && D == 128 && (dt == MH_BF16 || dt == MH_F16))
-    return launch_attn_fwd_wide(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
+  if (g_attn_fwd_pingpong && D == 128 && (dt == MH_BF16 || dt == MH_F16))
+    return launch_attn_fwd_pingpong(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
   Fwd2Args a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (uint16_t*)o;
   a.lse = lse; a.seqlens = seqlens; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;

@@ -1,16 +1,28 @@
-// Flash attention forward, WIDE form (gfx950, D = 128): ONE wave per SIMD, 64 queries per wave.
+// Flash attention forward, PING-PONG form (gfx950, D = 128): the two waves of a SIMD are kept in opposite phases.
 //
-// Same mathematics, tile machinery (attn_tiles.h) and MFMA orientation as attn_fwd2.hip
-//     S^T[kv, q] = K Q^T,   O^T[d, q] += V^T P^T   (32x32x16; a lane owns one query row of each 32-query block)
-// but a block is 4 waves x 64 queries = 256 query rows and runs alone on its CU with the whole 512-register file:
-//   * every K row fragment and every transposed V fragment read from LDS feeds TWO MFMAs (the wave's two 32-query blocks): half the
-//     LDS bytes per flop of the 32-query form, and a K|V tile is staged once per 256 instead of 128 queries;
-//   * register classes are fixed by hand (inline-asm MFMAs): O accumulators and the Q fragments live in AccVGPRs, score accumulators
-//     and P fragments in VGPRs, so the softmax arithmetic never moves data between the two files (left to hipcc, every accumulator of a
-//     kernel that needs AccVGPRs at all sits there and each score is copied out first);
-//   * the first MFMA of a score chain takes C = 0: no zero-fill of the 64 score registers per tile.
-// mh_attn_fwd_wide(1) selects it for D = 128 (A/B against attn_fwd2: profiles/r03_attn_fwd_wide_ab.txt).
+// Same mathematics, tile machinery (attn_tiles.h), MFMA orientation and per-wave work as attn_fwd2.hip
+//     S^T[kv, q] = K Q^T,   O^T[d, q] += V^T P^T   (32x32x16; 32 queries per wave, one query row per lane of a half-wave)
+// but a block is 8 waves (256 queries) on one CU instead of two independent 4-wave blocks.  Measured on attn_fwd2
+// (profiles/r03_attn_fwd_pingpong.txt): going from one to two free-running waves per SIMD buys only 19 % - the two waves fall into
+// step, both in their MFMA section or both in their softmax section.  Here a wave's tile loop is cut into
+//     M(t) = { O += V(t-1) P(t-1) ;  S(t) = K(t) Q^T }     32 MFMAs, no VALU work to speak of
+//     V(t) = { softmax of S(t) -> P(t), rescale }          VALU / transcendental only, no MFMA, no LDS
+// with a workgroup barrier behind every section, and waves 4-7 (the SIMD partners of waves 0-3) run one section behind: while one
+// wave of a SIMD issues MFMAs the other issues the exponentials, by construction.
+//
+// K|V tiles go through a ring of three LDS stages (tile t+1 is requested one whole iteration before its first use: the stage it
+// replaces was last read in M(t-1), and the lagging group leaves M(t-1) one barrier after the leading one); waves 0-3 copy the K
+// half of a stage, waves 4-7 the V half.
+//
+// Result (same file): in shader cycles the overlap is there (3240 cycles per tile pair against 2750 for the M sections alone and
+// 2650 for the V sections alone), but the part is power-limited and answers the denser instruction mix with a lower clock (1.65 GHz
+// against 2.07 / 2.11 GHz for either half alone): +5 % without a mask, -3 % causal (256-query blocks leave a coarser diagonal).
+// Outputs are bit-identical to attn_fwd2's.  Opt-in A/B arm: mh_attn_fwd_pingpong(1) selects it for D = 128; default off.
 #include "attn_tiles.h"
+
+#ifndef PP_PROBE
+#define PP_PROBE 0  // development: 1 = no V sections, 2 = no M sections, 3 = no staging, 4 = cycles per tile into lse (timing only, wrong results)
+#endif
 
 namespace mhattn {
 namespace {
@@ -30,54 +42,41 @@ __device__ __forceinline__ void lgkm_wait3() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-// score MFMAs: accumulator in VGPRs, B operand (Q fragment) in AccVGPRs; FIRST = start the chain from C = 0
-template <int DT, bool FIRST>
-__device__ __forceinline__ void mfma_s(f32x16_t& acc, const u32x4_t& kfrag, const u32x4_t& qfrag) {
-  if constexpr (FIRST) {
-    if constexpr (DT == MH_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kfrag), "a"(qfrag));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kfrag), "a"(qfrag));
-  } else {
-    if constexpr (DT == MH_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kfrag), "a"(qfrag));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(kfrag), "a"(qfrag));
-  }
+__device__ __forceinline__ float max_halves(float x) {  // max over lane, lane ^ 32 without LDS traffic (the lgkm counter belongs to the fragment windows)
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-// output MFMAs: accumulator pinned in AccVGPRs
-template <int DT>
-__device__ __forceinline__ void mfma_o(f32x16_t& acc, const u32x4_t& vfrag, const u32x4_t& pfrag) {
-  if constexpr (DT == MH_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(vfrag), "v"(pfrag));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(vfrag), "v"(pfrag));
+__device__ __forceinline__ float sum_halves(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// hipcc cannot see that the asm statements are MFMAs: the wait states it would insert are written out
-__device__ __forceinline__ void settle_v(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) {  // last score MFMA -> first VALU read
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-__device__ __forceinline__ void ready_p(u32x4_t (&p)[2][4]) {  // VALU write -> MFMA read (every P fragment is an operand: none may be packed later)
-  asm volatile("s_nop 1" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[1][0]), "+v"(p[1][1]), "+v"(p[1][2]), "+v"(p[1][3]));
-}
-__device__ __forceinline__ void settle_a(f32x16_t& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a)); }
-__device__ __forceinline__ void drain_o(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d, f32x16_t& e, f32x16_t& f, f32x16_t& g, f32x16_t& h) {
-  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f), "+a"(g), "+a"(h));
-}
-template <int OFF>
-__device__ __forceinline__ void gload128_a(u32x4_t& d, const void* ptr) {
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(d) : "v"(ptr), "n"(OFF) : "memory");
+constexpr int PP_W = 4;  // fragment read-ahead of a section M
+// LDS operations that may still be in flight when fragment g of a section is consumed: the next PP_W-1 fragments
+// (fragments [0, NV) are transposed V fragments = two reads each, [NV, NF) K row fragments = one read each)
+template <int NV, int NF>
+constexpr int pp_allowed(int g) {
+  int n = 0;
+  for (int h = g + 1; h <= g + PP_W - 1 && h < NF; ++h) n += (h < NV) ? 2 : 1;
+  return n;
 }
 
 template <int DT, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_fwd3_k(Fwd3Args a) {
+__global__ __launch_bounds__(512, 1) void attn_fwd3_k(Fwd3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 128;
   constexpr int RB = D * 2;               // bytes per tile row
   constexpr int T_BYTES = 64 * RB;        // one [64][D] tile
   constexpr int STAGE = 2 * T_BYTES;      // K, V
   constexpr int KSTEPS = D / 16, DBLK = D / 32;
-  constexpr int NKF = 2 * KSTEPS;         // K fragments per tile (2 key blocks x 8 k-steps)
-  constexpr int WK = 8;                   // K read window (fragments)
-  constexpr int NVF = DBLK * 4;           // V^T fragments per tile (d-block i, k-step s)
   constexpr int QROWS = 256;              // query rows per block
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;              // 0: leading group (waves 0-3), 1: their SIMD partners (wave w+4 shares a SIMD with wave w:
+                                          // measured - any other split runs 20 % slower), one section behind
+  const int role = wave >> 2;             // which half of a stage the wave copies (0: K, 1: V)
   const int l31 = lane & 31, hi = lane >> 5;
   const int nq = (a.S + QROWS - 1) / QROWS;
   int bh, qi;
@@ -87,52 +86,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd3_k(Fwd3Args a) {
   const int S = a.S;
   const int len = a.seqlens ? min(a.seqlens[b], S) : S;
   const int q0 = qblk * QROWS;
-  const int qw0 = q0 + wave * 64;
-  const int qrow0 = qw0 + l31, qrow1 = qrow0 + 32;
+  const int qw0 = q0 + wave * 32;
+  const int qrow = qw0 + l31;
 
   if (q0 >= len) {  // whole block is padding: zeros (pad_input semantics)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qr = qrow0 + 32 * qb;
-      if (qr < S) {
-        uint16_t* op = a.o + ((int64_t)b * S + qr) * a.ldo + (int64_t)h * D;
-        for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) *(uint2*)(op + d) = make_uint2(0, 0);
-        if (hi == 0) a.lse[((int64_t)b * a.H + h) * a.S_pad + qr] = 0.f;
-      }
+    if (qrow < S) {
+      uint16_t* op = a.o + ((int64_t)b * S + qrow) * a.ldo + (int64_t)h * D;
+      for (int d = hi * (D / 2); d < (hi + 1) * (D / 2); d += 4) *(uint2*)(op + d) = make_uint2(0, 0);
+      if (hi == 0) a.lse[((int64_t)b * a.H + h) * a.S_pad + qrow] = 0.f;
     }
     return;
   }
   const int kv_end = CAUSAL ? min(len, q0 + QROWS) : len;
-  const int ntiles = (kv_end + 63) / 64;
+  const int ntiles = (kv_end + 63) / 64;                           // K|V tiles the block stages (every wave takes part)
 
-  // Q fragments (B operand of S^T) straight into AccVGPRs: lane holds Q[qrow][16*ks + 8*hi .. +8]; waited for by the first tile's vmcnt(0)
-  u32x4_t qf[2][KSTEPS];
+  // Q fragments (B operand of S^T): lane holds Q[qrow][16*ks + 8*hi .. +8]
+  u32x4_t qf[KSTEPS];
   {
-    const uint16_t* qp0 = a.q + ((int64_t)b * S + min(qrow0, S - 1)) * a.ldq + (int64_t)h * D + 8 * hi;
-    const uint16_t* qp1 = a.q + ((int64_t)b * S + min(qrow1, S - 1)) * a.ldq + (int64_t)h * D + 8 * hi;
-    static_for<KSTEPS>([&](auto I) {
-      constexpr int ks = decltype(I)::value;
-      gload128_a<32 * ks>(qf[0][ks], qp0);
-      gload128_a<32 * ks>(qf[1][ks], qp1);
-    });
+    const uint16_t* qp = a.q + ((int64_t)b * S + min(qrow, S - 1)) * a.ldq + (int64_t)h * D + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const u32x4_t*)(qp + 16 * ks);
   }
-  const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
-  const uint16_t* vbase = a.v + (int64_t)b * S * a.ldv + (int64_t)h * D;
-  const auto so_k = stage_offsets<D, 64>(a.ldk, tid), so_v = stage_offsets<D, 64>(a.ldv, tid);
-  auto stage = [&](int s, int kv0) {
-    char* base = smem + s * STAGE;
-    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave, so_k);
-    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave, so_v);
+  // waves 0-3 copy the K tile of a stage, waves 4-7 its V tile
+  const uint16_t* cbase = (role == 0 ? a.k + (int64_t)b * S * a.ldk : a.v + (int64_t)b * S * a.ldv) + (int64_t)h * D;
+  const int64_t cld = role == 0 ? a.ldk : a.ldv;
+  const auto so_c = stage_offsets<D, 64>(cld, tid & 255);
+  auto stage = [&](int t) {
+    stage_rows<D, 64>(cbase, cld, t * 64, S - 1, smem + (t % 3) * STAGE + role * T_BYTES, tid & 255, wave & 3, so_c);
   };
 
-  f32x16_t o[2][DBLK];
+  f32x16_t o[DBLK];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-    for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
   const float sc = a.scale_log2;
 
   const unsigned lds0 = lds_addr_of(smem);
@@ -140,181 +128,173 @@ __global__ __launch_bounds__(256, 1) void attn_fwd3_k(Fwd3Args a) {
   row_frag_offsets<D>(l31, hi, off_k);
   tr_frag_offsets<D>(lane, off_v);
 
-  auto tile = [&](int j, auto EDGE_) {
-    constexpr bool EDGE = decltype(EDGE_)::value;
-    const int kv0 = j * 64;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < ntiles) stage((j + 1) & 1, kv0 + 64);
-    if constexpr (EDGE) {
-      if (CAUSAL && kv0 > qw0 + 63) return;  // tile entirely above this wave's diagonal (wave-uniform)
+  f32x16_t st[2];      // S(t) of the wave's 32 queries x 64 keys, then P(t)
+  u32x4_t pf[4];       // P(t) as four B-operand fragments
+  u32x2_t wv[2 * PP_W];  // fragment read-ahead windows of a section M (a V^T fragment = two transpose-reads; assembled AFTER its wait)
+  u32x4_t wk[PP_W];
+
+  // fragment g of section M(t): g < NV -> V^T fragment (d-block g/4, k-step g%4) of tile t-1; else K row fragment n = g - NV
+  // (key block n/8, k-step n%8) of tile t
+  auto issue = [&](auto G, auto NV_, unsigned kb, unsigned vb) __attribute__((always_inline)) {
+    constexpr int g = decltype(G)::value, NV = decltype(NV_)::value;
+    if constexpr (g < NV) {
+      lds_read64_tr<((g % 4) * 16) * RB>(wv[2 * (g % PP_W)], vb + off_v[2 * (g / 4)]);
+      lds_read64_tr<((g % 4) * 16 + 8) * RB>(wv[2 * (g % PP_W) + 1], vb + off_v[2 * (g / 4) + 1]);
+    } else {
+      constexpr int n = g - NV;
+      lds_read128<(n / KSTEPS) * 32 * RB>(wk[g % PP_W], kb + off_k[n % KSTEPS]);
     }
-    const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
-    unsigned ak[KSTEPS], av[KSTEPS];
+  };
+  // M(t): O += V(t-1) P(t-1), then S(t) = K(t) Q^T.  One form only: M(0) multiplies the zero-filled stage 2 by P = 0, and the
+  // S half of a wave's last M (t = nt_w) reads a stale stage and is never looked at.
+  auto section_m = [&](int t) __attribute__((always_inline)) {
+    constexpr int NV = 16, NF = 32;
+    const unsigned kb = lds0 + (unsigned)(t % 3) * STAGE, vb = lds0 + (unsigned)((t + 2) % 3) * STAGE + T_BYTES;
+    static_for<PP_W>([&](auto G) { issue(G, std::integral_constant<int, NV>{}, kb, vb); });
+    prio_mfma(true);
+    static_for<NF>([&](auto G) {
+      constexpr int g = decltype(G)::value;
+      lgkm_wait3<pp_allowed<NV, NF>(g)>();
+      if constexpr (g < NV) {
+        const u32x4_t vf = u32x4_t{wv[2 * (g % PP_W)][0], wv[2 * (g % PP_W)][1], wv[2 * (g % PP_W) + 1][0], wv[2 * (g % PP_W) + 1][1]};
+        o[g / 4] = mfma32v<DT>(vf, pf[g % 4], o[g / 4]);
+      } else {
+        constexpr int n = g - NV;
+        if constexpr (n % KSTEPS == 0) {  // (the score accumulators are born here, not at the top of the section: 32 registers)
 #pragma unroll
-    for (int i = 0; i < KSTEPS; ++i) {
-      ak[i] = sb + off_k[i];
-      av[i] = sb + T_BYTES + off_v[i];
-    }
-
-    // ---- S^T = K Q^T: fragment n = (key block n / KSTEPS, k-step n % KSTEPS) feeds the two query blocks; rolling window of WK reads ----
-    f32x16_t st[2][2];  // [query block][key block]
-    u32x4_t wk[WK];
-    static_for<WK>([&](auto I) {
-      constexpr int n = decltype(I)::value;
-      lds_read128<(n / KSTEPS) * 32 * RB>(wk[n % WK], ak[n % KSTEPS]);
-    });
-    static_for<NKF>([&](auto I) {
-      constexpr int n = decltype(I)::value;
-      constexpr int left = NKF - 1 - n;
-      lgkm_wait3<(left < WK - 1 ? left : WK - 1)>();
-      mfma_s<DT, (n % KSTEPS) == 0>(st[0][n / KSTEPS], wk[n % WK], qf[0][n % KSTEPS]);
-      mfma_s<DT, (n % KSTEPS) == 0>(st[1][n / KSTEPS], wk[n % WK], qf[1][n % KSTEPS]);
-      if constexpr (n + WK < NKF) lds_read128<((n + WK) / KSTEPS) * 32 * RB>(wk[n % WK], ak[(n + WK) % KSTEPS]);
-    });
-
-    // ---- first V^T fragments go out now; their latency hides under the softmax ----
-    u32x2_t wv[8];  // window of 4 fragments = 8 transpose-reads
-    static_for<4>([&](auto I) {
-      constexpr int f = decltype(I)::value;  // f = i*4 + s
-      lds_read64_tr<((f % 4) * 16) * RB>(wv[2 * f], av[2 * (f / 4)]);
-      lds_read64_tr<((f % 4) * 16 + 8) * RB>(wv[2 * f + 1], av[2 * (f / 4) + 1]);
-    });
-    settle_v(st[0][0], st[0][1], st[1][0], st[1][1]);
-
-    // ---- mask (boundary tiles only) + online softmax per query block (one query row per lane; lane^32 holds the other 32 keys) ----
-    u32x4_t pf[2][4];
-    float alpha[2];
-    bool need_any = false;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qrow = qrow0 + 32 * qb;
-      if (EDGE && ((kv0 + 64 > len) || (CAUSAL && (kv0 + 63 > qw0 + 32 * qb)))) {
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kv = kv0 + 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool ok = (kv < len) && (!CAUSAL || kv <= qrow);
-            st[qb][blk][r] = ok ? st[qb][blk][r] : -INFINITY;
-          }
+          for (int r = 0; r < 16; ++r) st[n / KSTEPS][r] = 0.f;
+        }
+        st[n / KSTEPS] = mfma32v<DT>(wk[g % PP_W], qf[n % KSTEPS], st[n / KSTEPS]);
       }
-      float mx = st[qb][0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[qb][0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[qb][1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // lazy rescaling (see attn_fwd2.hip): the reference only moves when a row maximum grows by more than 2^8
-      const float m_new = fmaxf(m_run[qb], mx * sc);
-      const bool need = m_new > m_run[qb] + 8.0f;
-      alpha[qb] = 1.0f;
-      if (need) {
-        alpha[qb] = fast_exp2(m_run[qb] - m_new);  // (first tile: exp2(-inf) = 0)
-        m_run[qb] = m_new;
-      }
-      need_any |= need;
-      const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];  // rows with every key masked so far
-      float psum = 0.f;
+      if constexpr (g + PP_W < NF) issue(std::integral_constant<int, g + PP_W>{}, std::integral_constant<int, NV>{}, kb, vb);
+    });
+    prio_mfma(false);
+  };
+  // mask (boundary tiles only) + online softmax of S(t): one query row per lane, lane ^ 32 holds the other 32 keys of the tile
+  auto section_v = [&](int t) __attribute__((always_inline)) {
+    const int kv0 = t * 64;
+    if ((kv0 + 64 > len) || (CAUSAL && (kv0 + 63 > qw0))) {
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = fast_exp2(fmaf(st[qb][blk][r], sc, -m_use));
-          st[qb][blk][r] = p;
-          psum += p;
-        }
-      l_run[qb] = l_run[qb] * alpha[qb] + psum;
-      // P fragments: k-step s uses regs 8*(s&1)..+7 of key block s>>1
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float t[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = st[qb][s >> 1][8 * (s & 1) + e];
-        pf[qb][s] = pack8v<DT>(t);
-      }
-    }
-    if (__builtin_amdgcn_ballot_w64(need_any) != 0) {  // wave-uniform, rare after the first tiles
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < DBLK; ++i) {
-          settle_a(o[qb][i]);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha[qb];
-          asm volatile("s_nop 1" : "+a"(o[qb][i]));
+          const int kv = kv0 + 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = (kv < len) && (!CAUSAL || kv <= qrow);
+          st[blk][r] = ok ? st[blk][r] : -INFINITY;
         }
     }
-    ready_p(pf);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- O^T += V^T P^T: fragment f = (d-block f/4, k-step f%4) feeds the two query blocks; rolling window of 4 fragments ----
-    static_for<NVF>([&](auto I) {
-      constexpr int f = decltype(I)::value;
-      constexpr int left = NVF - 1 - f;
-      lgkm_wait3<2 * (left < 3 ? left : 3)>();
-      const u32x4_t vf = u32x4_t{wv[2 * (f % 4)][0], wv[2 * (f % 4)][1], wv[2 * (f % 4) + 1][0], wv[2 * (f % 4) + 1][1]};
-      mfma_o<DT>(o[0][f / 4], vf, pf[0][f % 4]);
-      mfma_o<DT>(o[1][f / 4], vf, pf[1][f % 4]);
-      if constexpr (f + 4 < NVF) {
-        constexpr int g = f + 4;
-        lds_read64_tr<((g % 4) * 16) * RB>(wv[2 * (f % 4)], av[2 * (g / 4)]);
-        lds_read64_tr<((g % 4) * 16 + 8) * RB>(wv[2 * (f % 4) + 1], av[2 * (g / 4) + 1]);
+    float mx = st[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+    mx = max_halves(mx);
+    // lazy rescaling (see attn_fwd2.hip): the reference only moves when a row maximum grows by more than 2^8
+    const float m_new = fmaxf(m_run, mx * sc);
+    const bool need = m_new > m_run + 8.0f;
+    float alpha = 1.0f;
+    if (need) {
+      alpha = fast_exp2(m_run - m_new);  // (first tile: exp2(-inf) = 0)
+      m_run = m_new;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;  // rows with every key masked so far
+    float psum = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(st[blk][r], sc, -m_use));
+        st[blk][r] = p;
+        psum += p;
       }
-    });
-    // the register allocator moves accumulators between the two loops and the finalize (AccVGPR copies on the loop-exit
-    // edge, straight behind the last MFMA whose latency it cannot see): every tile ends with the MFMA -> VALU wait states
-    static_assert(DBLK == 4, "drain_o lists the accumulators");
-    drain_o(o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]);
-  };
-  // tiles [0, n_full) need no masking for any wave of this block
-  const int n_full = min(ntiles, CAUSAL ? min(q0, len) / 64 : len / 64);
-  stage(0, 0);
-  for (int j = 0; j < n_full; ++j) tile(j, std::false_type{});
-  for (int j = n_full; j < ntiles; ++j) tile(j, std::true_type{});
-
-  // ---- finalize ----
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = qrow0 + 32 * qb;
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const bool valid = (qrow < len);
-    const float inv = (valid && l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i) settle_a(o[qb][i]);
-    if (qrow < S) {
-      uint16_t* op = a.o + ((int64_t)b * S + qrow) * a.ldo + (int64_t)h * D;
+    l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform, rare after the first tiles
 #pragma unroll
       for (int i = 0; i < DBLK; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = 32 * i + 8 * g + 4 * hi;
-          *(uint2*)(op + d) = make_uint2(pack2<DT>(o[qb][i][4 * g + 0] * inv, o[qb][i][4 * g + 1] * inv),
-                                         pack2<DT>(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv));
-        }
-      if (hi == 0)
-        a.lse[((int64_t)b * a.H + h) * a.S_pad + qrow] = (valid && l_tot > 0.f) ? (m_run[qb] + log2f(l_tot)) * 0.6931471805599453f : 0.f;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
+    // P fragments: k-step s uses regs 8*(s&1)..+7 of key block s>>1
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float t8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t8[e] = st[s >> 1][8 * (s & 1) + e];
+      pf[s] = pack8v<DT>(t8);
+    }
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) pf[s4] = u32x4_t{0u, 0u, 0u, 0u};
+  for (int i = tid; i < T_BYTES / 16; i += 512) *(uint4*)(smem + 2 * STAGE + T_BYTES + i * 16) = make_uint4(0, 0, 0, 0);  // "V(-1)"
+  stage(0);
+  if (ntiles > 1) stage(1);
+  landed();
+  bar();
+  // Barrier n (n = 1, 2, ...): the leading group passes it after M(t) (n = 2t+1) and after V(t) (n = 2t+2), the lagging group before
+  // M(0) (n = 1), after M(t) (n = 2t+2) and after V(t) (n = 2t+3).  The stage of tile t-2 was last read in M(t-1), which both groups
+  // have left at barrier 2t: tile t+1 is requested behind it and has landed, for every wave, at barrier 2t+2.
+  // Both groups run M(0) V(0) M(1) V(1) ... M(ntiles) with a barrier behind every section; the lagging group starts one barrier late.
+  // Every wave computes on every tile of the block: the tiles above a wave's own causal diagonal are fully masked (P = 0) and cost
+  // nothing - the wave would wait at the barriers anyway - and sections without conditions keep the register allocation simple.
+  const long long pp_t0 = (PP_PROBE >= 4) ? __builtin_readcyclecounter() : 0;
+  if (grp) bar();
+  for (int t = 0; t < ntiles; ++t) {
+    if (PP_PROBE != 3 && !grp && t >= 1 && t + 1 < ntiles) stage(t + 1);
+    if (PP_PROBE != 2 && PP_PROBE != 6) section_m(t);
+    if (grp) landed();
+    bar();
+    if (PP_PROBE != 3 && grp && t + 2 < ntiles) stage(t + 2);
+    if (PP_PROBE != 1 && PP_PROBE != 5) section_v(t);
+    if (!grp) landed();
+    bar();
   }
+  section_m(ntiles);  // the last tile's P V (its S half reads a stale stage and is never looked at)
+  if (!grp) bar();
+  const long long pp_t1 = (PP_PROBE >= 4) ? __builtin_readcyclecounter() : 0;
+
+  // ---- finalize ----
+  const float l_tot = sum_halves(l_run);
+  const bool valid = (qrow < len);
+  const float inv = (valid && l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (qrow < S) {
+    uint16_t* op = a.o + ((int64_t)b * S + qrow) * a.ldo + (int64_t)h * D;
+#pragma unroll
+    for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * i + 8 * g + 4 * hi;
+        *(uint2*)(op + d) = make_uint2(pack2<DT>(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv),
+                                       pack2<DT>(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv));
+      }
+    if (hi == 0)
+      a.lse[((int64_t)b * a.H + h) * a.S_pad + qrow] = (valid && l_tot > 0.f) ? (m_run + log2f(l_tot)) * 0.6931471805599453f : 0.f;
+  }
+  if (PP_PROBE >= 4 && tid == 0) a.lse[((int64_t)b * a.H + h) * a.S_pad + q0] = (float)(pp_t1 - pp_t0) / (float)ntiles;
 }
 
 template <int DT, bool CAUSAL>
 int launch_fwd3(const Fwd3Args& a, hipStream_t st) {
-  constexpr size_t lds = 2 * 2 * 64 * 128 * 2;
+  constexpr size_t lds = 3 * 2 * 64 * 128 * 2;  // ring of three K|V stages
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_fwd3_k<DT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_fwd3_k<DT, CAUSAL>), dim3(xcd_grid(a.B * a.H, (a.S + 255) / 256)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd3_k<DT, CAUSAL>), dim3(xcd_grid(a.B * a.H, (a.S + 255) / 256)), dim3(512), lds, st, a);
   MH_LAUNCH_CHECK();
 }
 
 }  // namespace
 
-// D = 128 forward in the wide form (called by mh_attn_fwd2 when mh_attn_fwd_wide(1) is set)
-int launch_attn_fwd_wide(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
+// D = 128 forward in the ping-pong form (called by mh_attn_fwd2 when mh_attn_fwd_pingpong(1) is set)
+int launch_attn_fwd_pingpong(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
                          const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st) {
   Fwd3Args a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (uint16_t*)o;

@@ -956,9 +956,9 @@ def gemv_mfma_wide(on: bool):
     L.lib().mh_gemv_mfma_wide(i32(1 if on else 0))
 
 
-def attn_fwd_wide(on: bool):
-    """A/B switch: D = 128 attention forward in the wide form (one wave per SIMD, 64 queries per wave; csrc/attn_fwd3.hip)."""
-    L.lib().mh_attn_fwd_wide(i32(int(on)))
+def attn_fwd_pingpong(on: bool):
+    """A/B switch: D = 128 attention forward in the ping-pong form (8-wave blocks, SIMD partners in opposite phases; csrc/attn_fwd3.hip)."""
+    L.lib().mh_attn_fwd_pingpong(i32(int(on)))
 
 
 def attn_bwd_fused_kv(on: bool):

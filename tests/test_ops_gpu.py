@@ -975,8 +975,8 @@ def test_gemm_fp8_fused_rope_and_swiglu_match_unfused(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,H,causal,ragged", [(2, 256, 2, True, False), (1, 1000, 3, True, False), (2, 613, 2, True, True), (1, 1536, 2, False, False),
                                                   (3, 700, 1, False, True), (1, 4096, 2, True, False), (2, 2432, 1, True, True)])
-def test_attention_forward_wide_form_matches(ops, dtype, B, S, H, causal, ragged):
-    """csrc/attn_fwd3.hip (mh_attn_fwd_wide(1): one wave per SIMD, 64 queries per wave, 256-query blocks) against the 128-query form
+def test_attention_forward_pingpong_form_matches(ops, dtype, B, S, H, causal, ragged):
+    """csrc/attn_fwd3.hip (mh_attn_fwd_pingpong(1): 8-wave 256-query blocks, SIMD partners in opposite phases) against the 128-query form
     (itself held to a chunked fp32 reference elsewhere in this file) and against fp32 torch on one head: ragged lengths, sequence
     lengths that are not a multiple of the 256-row block, causal and not, padded rows zero."""
     D = 128
@@ -987,13 +987,13 @@ def test_attention_forward_wide_form_matches(ops, dtype, B, S, H, causal, ragged
     if ragged:
         lens = torch.tensor([max(1, S - 37 * (b + 1) - (b * 211) % S // 3) for b in range(B)], dtype=torch.int32, device="cuda")
     try:
-        ops.attn_fwd_wide(False)
+        ops.attn_fwd_pingpong(False)
         o0, l0 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
-        ops.attn_fwd_wide(True)
+        ops.attn_fwd_pingpong(True)
         o1, l1 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
         o2, _ = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
     finally:
-        ops.attn_fwd_wide(False)
+        ops.attn_fwd_pingpong(False)
     assert torch.equal(o1, o2)  # deterministic
     assert relerr(o1, o0.float()) < 2 * EPS16[dtype], relerr(o1, o0.float())
     assert float((l1[:, :, :S] - l0[:, :, :S]).abs().max()) < 1e-3

@@ -26,10 +26,10 @@ for B, S in ((8, 4096), (4, 8192)):
     dqkv = torch.empty_like(qkv)
     for causal in (True, False):
         o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=causal)
-        O.attn_fwd_wide(True)
+        O.attn_fwd_pingpong(True)
         tw = min(timeit(lambda: O.attn_fwd2(q, k, v, B, S, H, D, causal=causal, out=o, lse=lse)) for _ in range(2))
-        O.attn_fwd_wide(False)
-        print(f"B={B} S={S} causal={causal}: fwd WIDE {tw:.3f} ms ({4.0 * B * H * S * S * D * (0.5 if causal else 1.0) / tw / 1e9:.0f} TF)", flush=True)
+        O.attn_fwd_pingpong(False)
+        print(f"B={B} S={S} causal={causal}: fwd PING-PONG {tw:.3f} ms ({4.0 * B * H * S * S * D * (0.5 if causal else 1.0) / tw / 1e9:.0f} TF)", flush=True)
         tf = timeit(lambda: O.attn_fwd2(q, k, v, B, S, H, D, causal=causal, out=o, lse=lse))
         tb = timeit(lambda: O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, dq=dqkv[:, :H * D], dk=dqkv[:, H * D:2 * H * D], dv=dqkv[:, 2 * H * D:]))
         fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)

@@ -272,9 +272,11 @@ int mh_gemv_qkv_rope(const void* x, int64_t ldx, const void* norm_w, float eps, 
 int mh_decode_rope_append(void* qkv, const float* cos_sin, const int32_t* pos, const int32_t* rope_pos, void* kcache, void* vcache, int B,
                           int H, int D, int Smax, int dt, void* stream);
 /* out[b, h*D..] = softmax(q[b,h] . K[b, 0..lens[b]) / sqrt(D)) V[b, 0..lens[b]);  q row stride ldq; D in {64, 128}.
- * Split-KV: with ws != NULL (B*H*mh_attn_decode_splits(B,H,Smax)*(D+2) floats) several blocks share one (b, h) and a
- * second pass merges their partial softmaxes; ws == NULL runs one block per (b, h). */
+ * Split-KV: with ws != NULL (B*H*mh_attn_decode_splits(B,H,Smax)*(D+2) floats) several blocks share one (b, h) and a second
+ * launch merges their partial softmaxes; ws == NULL runs one block per (b, h).  mh_attn_decode_fused_merge(1): the last block of a
+ * (b, h) to finish merges instead (ticket counters inside the library: one decode stream at a time; A-B arm, default off). */
 int mh_attn_decode_splits(int B, int H, int Smax);
+void mh_attn_decode_fused_merge(int on);
 int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, void* out, const int32_t* lens,
                    int B, int H, int D, int Smax, float* ws, int dt, void* stream);
 

@@ -800,15 +800,21 @@ __global__ __launch_bounds__(256) void rope_append_k(uint16_t* __restrict__ qkv,
   *(uint4*)(vdst + half) = *(const uint4*)(vb + half);
 }
 
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ticket counters of the split-KV merge, one per (b, h): zero at load, left zero by every launch (one decode stream at a time)
+__device__ unsigned g_decode_tickets[16384];
+
 // q [B, ldq] (head h at h*D); kc, vc [B, Smax, H*D]; out [B, H*D]; keys [0, len[b]).  D in {64, 128}.
 // Split-KV ("flash decoding"): with B*H blocks only (32 at batch 1) the cache streams at a few % of HBM speed, so
 // `splits` blocks share one (b, h), each takes `chunk` keys and leaves (unnormalised o[D], max, sum) in `ws`;
-// attn_decode_combine_k merges them.  splits == 1 writes the normalised result directly.
+// attn_decode_combine_k merges them as a second launch (cnt == NULL, the default) - or the last of the blocks to finish does
+// (cnt != NULL: mh_attn_decode_fused_merge(1), an A/B arm that measured no faster).  splits == 1 writes the normalised result directly.
 template <int DT, int D>
 __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kc,
                                                      const uint16_t* __restrict__ vc, uint16_t* __restrict__ out,
                                                      const int32_t* __restrict__ lens, int H, int Smax, float scale_log2,
-                                                     int splits, int chunk, float* __restrict__ ws) {
+                                                     int splits, int chunk, float* __restrict__ ws, unsigned* __restrict__ cnt) {
   extern __shared__ float sc[];  // [chunk] scores, then [G][D] partial outputs
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -903,9 +909,53 @@ __global__ __launch_bounds__(256) void attn_decode_k(const uint16_t* __restrict_
       out[(int64_t)b * HD + (int64_t)h * D + tid] = (uint16_t)st16<DT>(len > 0 ? a / sum : 0.f);
     } else {
       float* w = ws + ((int64_t)(b * H + h) * splits + sp) * (D + 2);
-      w[tid] = a;
-      if (tid == 0) { w[D] = mx; w[D + 1] = sum; }
+      if (cnt) {  // device-coherent stores: the merging block may sit on another XCD (its L2 is not this one's)
+        st_agent(w + tid, a);
+        if (tid == 0) { st_agent(w + D, mx); st_agent(w + D + 1, sum); }
+      } else {
+        w[tid] = a;
+        if (tid == 0) { w[D] = mx; w[D + 1] = sum; }
+      }
     }
+  }
+  if (splits == 1 || !cnt) return;
+  // The last of the `splits` blocks of this (b, h) to get here merges the partial softmaxes: no second launch (at batch 1 the merge
+  // kernel is 5.6 us of dependent round trips per layer - and so is this tail: no gain).  Ticket counter per (b, h), reset by its last taker.
+  // (no __threadfence: at agent scope it writes back and invalidates the whole L2 - measured 150 us per layer.  The partials are
+  //  written and read with device-coherent accesses, so all the release needs is that this block's stores have completed)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(cnt + (b * H + h), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (t == (unsigned)splits - 1u);
+    if (last) __hip_atomic_store(cnt + (b * H + h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[0] = last ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (red[0] == 0.f) return;
+  asm volatile("" ::: "memory");
+  if (tid < D) {
+    const float* w = ws + (int64_t)(b * H + h) * splits * (D + 2);
+    float v[32], sm_[32], sl_[32];
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {  // every partial is requested before any is used
+      v[s2] = s2 < splits ? ld_agent(w + s2 * (D + 2) + tid) : 0.f;
+      sm_[s2] = s2 < splits ? ld_agent(w + s2 * (D + 2) + D) : -1e30f;
+      sl_[s2] = s2 < splits ? ld_agent(w + s2 * (D + 2) + D + 1) : 0.f;
+    }
+    float M = -1e30f;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) M = fmaxf(M, sm_[s2]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+      if (s2 < splits) {
+        const float f = fast_exp2(sm_[s2] - M);
+        num += v[s2] * f;
+        den += sl_[s2] * f;
+      }
+    }
+    out[(int64_t)b * HD + (int64_t)h * D + tid] = (uint16_t)st16<DT>(den > 0.f ? num / den : 0.f);
   }
 }
 
@@ -1064,6 +1114,8 @@ extern "C" int mh_decode_rope_append(void* qkv, const float* cos_sin, const int3
   MH_LAUNCH_CHECK();
 }
 
+static int g_decode_fused_merge = 0;  // 1: split-KV merge by the last block of a (b, h) instead of a second launch (A-B arm: measured 0.3-1 % slower, profiles/r03_decode_nt_ab.txt)
+extern "C" void mh_attn_decode_fused_merge(int on) { g_decode_fused_merge = on ? 1 : 0; }
 extern "C" int mh_attn_decode_splits(int B, int H, int Smax) {
   int s = (1024 + B * H - 1) / (B * H);
   const int by_len = (Smax + 127) / 128;  // >= 128 keys per split
@@ -1085,6 +1137,12 @@ extern "C" int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, co
   if (lds > 150 * 1024) return MH_ERR_SHAPE;  // <= 38400 keys per split
   const dim3 grid(B * H * splits), block(256);
   hipStream_t st = as_stream(stream);
+  unsigned* cnt = nullptr;
+  if (splits > 1 && g_decode_fused_merge && B * H <= 16384) {
+    static unsigned* tickets = nullptr;
+    if (!tickets && hipGetSymbolAddress((void**)&tickets, HIP_SYMBOL(g_decode_tickets)) != hipSuccess) tickets = nullptr;
+    cnt = tickets;
+  }
 #define GO(DT_, D_)                                                                                                     \
   do {                                                                                                                   \
     static bool attr = false;                                                                                           \
@@ -1093,8 +1151,8 @@ extern "C" int mh_attn_decode(const void* q, int64_t ldq, const void* kcache, co
       attr = true;                                                                                                       \
     }                                                                                                                    \
     hipLaunchKernelGGL((attn_decode_k<DT_, D_>), grid, block, lds, st, (const uint16_t*)q, ldq, (const uint16_t*)kcache, \
-                       (const uint16_t*)vcache, (uint16_t*)out, lens, H, Smax, scale_log2, splits, chunk, ws);           \
-    if (splits > 1)                                                                                                      \
+                       (const uint16_t*)vcache, (uint16_t*)out, lens, H, Smax, scale_log2, splits, chunk, ws, cnt);      \
+    if (splits > 1 && !cnt)                                                                                              \
       hipLaunchKernelGGL((attn_decode_combine_k<DT_, D_>), dim3(B * H), dim3(D_), 0, st, (const float*)ws, (uint16_t*)out, H, splits); \
   } while (0)
   if (dt == MH_BF16) { if (D == 128) GO(MH_BF16, 128); else GO(MH_BF16, 64); }

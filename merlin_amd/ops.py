@@ -276,6 +276,11 @@ def attn_decode(q, kcache, vcache, lens, H, D, out=None, split_kv=True):
     return out
 
 
+def attn_decode_fused_merge(on: bool):
+    """A/B switch: split-KV partials merged by a second launch (default) or by the last block of a (b, h) to finish."""
+    L.lib().mh_attn_decode_fused_merge(i32(1 if on else 0))
+
+
 _splitk_ws = {}
 
 

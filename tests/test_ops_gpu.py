@@ -778,6 +778,12 @@ def test_decode_rope_append_and_attention(ops, dtype, B, H, D, Smax, lens):
     o = ops.attn_decode(qkv[:, :d], kc, vc, lens_t, H, D)
     o1 = ops.attn_decode(qkv[:, :d], kc, vc, lens_t, H, D, split_kv=False)  # one block per (b, h)
     assert relerr(o1, o.float()) < 2 * EPS16[dtype]
+    try:  # the split-KV merge by the last block of a (b, h) (A/B arm) against the merge as a second launch: same arithmetic, same bits
+        ops.attn_decode_fused_merge(True)
+        for _ in range(3):  # (the ticket counters are left at zero by every launch)
+            assert torch.equal(ops.attn_decode(qkv[:, :d], kc, vc, lens_t, H, D), o)
+    finally:
+        ops.attn_decode_fused_merge(False)
     for b in range(B):
         L_ = lens[b]
         qh = qkv[b, :d].float().view(H, 1, D)

@@ -16,6 +16,8 @@ if os.environ.get("MH_GEMV_MFMA_WIDE"):  # A/B: 0 = 8 waves per block in the sma
     _O.gemv_mfma_wide(os.environ["MH_GEMV_MFMA_WIDE"] != "0")
 if os.environ.get("MH_GEMV_KSPLIT"):  # A/B: 0 = one wave per row pair in the small-N GEMV
     _O.gemv_ksplit(os.environ["MH_GEMV_KSPLIT"] != "0")
+if os.environ.get("MH_DECODE_FUSED_MERGE"):  # A/B: 1 = split-KV partials merged by the last block of a (b, h) instead of a second launch
+    _O.attn_decode_fused_merge(os.environ["MH_DECODE_FUSED_MERGE"] != "0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 NEW = 160

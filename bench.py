@@ -353,7 +353,7 @@ def main(argv=None):
             batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
             if args.config == "cfg5":
                 args.fp8_train = True
-                workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers"
+                workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers and lm_head"
             else:
                 workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, bf16 weights (NOT cfg 5's fp8 weight path)"
         else:
@@ -362,6 +362,9 @@ def main(argv=None):
             workload = "single 336px image + 32-token caption (S=613), ViT-L/14-336 + mlp projector + Llama-7B"
         if args.fp8_train:
             model.fp8_training = True
+            if os.environ.get("MH_FP8_PARTS"):  # A/B: "decoder" = tower and head stay 16-bit; "decoder,tower" / "decoder,head"
+                parts = os.environ["MH_FP8_PARTS"].split(",")
+                model.engine.fp8_tower, model.engine.fp8_head = "tower" in parts, "head" in parts
         S = batch["input_ids"].shape[1]
         n_img = sum(int(im.shape[0]) for im in batch["images"])
         n_tok = int(batch["attention_mask"].sum())  # the metric counts sequence positions, padding excluded
@@ -481,7 +484,7 @@ def main(argv=None):
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("cpu-fp32 (dry run)" if dry else "fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
-                  "fp8-e4m3 decoder GEMMs fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / tower / head, fp32 accumulate)" if args.fp8_train else
+                  "fp8-e4m3 Linear GEMMs (decoder, lm_head) fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / norms / CLIP tower, fp32 accumulate)" if args.fp8_train else
                   "bf16 (fp32 residual streams)" if args.fp32_residual else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",

@@ -55,6 +55,10 @@ class HipEngine:
         self.strict_checks = True
         self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
         self.force_unpad = False  # tests: send right-padded masks through the general unpad / pad attention path as well
+        # fp8 training step beyond the decoder: lm_head on by default (-0.5 % of a cfg-5 step); the CLIP tower's Linears (K = 1024: their
+        # quantisation passes cost more than the fp8 MFMA returns, +0.6 %, profiles/r03_fp8_parts_ab.txt) implemented, tested, off by default
+        self.fp8_head = True
+        self.fp8_tower = False
         # opt-in: both towers' residual streams in fp32 (updated in place by the accumulating fp32 epilogue of the projections that feed
         # them, read by mh_norm_fwd_f32in); GEMM operands, attention and every saved activation stay 16-bit.  Forward parity at depth:
         # tests/test_model_gpu.py (full 7B) and profiles/r03_parity.txt; the backward is unchanged (16-bit copies of the layer inputs).
@@ -281,6 +285,90 @@ class HipEngine:
         self._ready(W.names)
         return dx
 
+    # ---- the same encoder layer with its four Linears on the scaled-fp8 MFMA (fp8 training step, BASELINE cfg 5: "all Llama / ViT
+    # Linear weights").  Operand formats as in the decoder (fp8_train_weights): activations / gradients row-quantised per token, the
+    # transposed wgrad operands per feature (gradients) or tensor-wide (activations), weights per output channel + 128-block exponents.
+    # LayerNorm, attention, quick-GELU, bias gradients and the residual stream stay 16-bit.
+    def fp8_tower_weights(self, li):
+        def make():
+            out = []
+            for W in self.vit:
+                out.append(dict(wqkv=O.quant_fp8_rows_e4(W.wqkv), wo=O.quant_fp8_rows_e4(W.wo), w1=O.quant_fp8_rows_e4(W.w1), w2=O.quant_fp8_rows_e4(W.w2),
+                                wqkvT=O.quant_fp8_rows_t_e4(W.wqkv), woT=O.quant_fp8_rows_t_e4(W.wo), w1T=O.quant_fp8_rows_t_e4(W.w1),
+                                w2T=O.quant_fp8_rows_t_e4(W.w2)))
+            return self._drop_zero_exponents(out)
+        return self._derive("fp8_tower_weights", make)[li]
+
+    def _vit_layer_fwd_fp8(self, W, li, x, N, S, vc, keep):
+        H = vc.num_attention_heads
+        vd = vc.hidden_size
+        D = vd // H
+        eps = vc.layer_norm_eps
+        Q = self.fp8_tower_weights(li)
+        dt = x.dtype
+        h1 = O.layernorm_fwd(x, W.ln1w, W.ln1b, eps)
+        a1 = O.quant_fp8_rows(h1)
+        qkv = O.gemm_fp8(a1, Q["wqkv"], out_dtype=dt, bias=W.bqkv)
+        q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
+        o, lse = O.attn_fwd2(q, k, v, N, S, H, D, causal=False)
+        a2 = O.quant_fp8_rows(o)
+        x2 = O.gemm_fp8(a2, Q["wo"], out_dtype=dt, bias=W.bo, resid=x)
+        h2 = O.layernorm_fwd(x2, W.ln2w, W.ln2b, eps)
+        a3 = O.quant_fp8_rows(h2)
+        if keep:
+            f1 = O.gemm_fp8(a3, Q["w1"], out_dtype=dt, bias=W.b1)
+            a = O.quick_gelu_fwd(f1)
+        else:
+            f1 = None
+            a = O.gemm_fp8(a3, Q["w1"], out_dtype=dt, bias=W.b1, act="quick_gelu")
+        a4 = O.quant_fp8_rows(a)
+        y = O.gemm_fp8(a4, Q["w2"], out_dtype=dt, bias=W.b2, resid=x2)
+        return y, ((h1, qkv, o, lse, x2, h2, f1, a, (a1[1], a2[1], a3[1], a4[1])) if keep else None)
+
+    def _vit_layer_bwd_fp8(self, W, li, x, dy, N, S, vc, saved, fresh):
+        A = self.arena
+        H = vc.num_attention_heads
+        vd = vc.hidden_size
+        D = vd // H
+        eps = vc.layer_norm_eps
+        if saved is None:
+            _, saved = self._vit_layer_fwd_fp8(W, li, x, N, S, vc, keep=True)
+        h1, qkv, o, lse, x2, h2, f1, a, (s_h1, s_o, s_h2, s_a) = saved
+        Q = self.fp8_tower_weights(li)
+        dt = x.dtype
+        p = W.p
+        acc = not fresh
+        # fc2
+        dy8, dyT8 = O.quant_fp8_both(dy)
+        da = O.gemm_fp8(dy8, Q["w2T"], out_dtype=dt)
+        self._wgrad_fp8(dyT8, a, s_a, A.gview(p + "mlp.fc2.weight"), fresh)
+        O.colsum(dy, A.gview(p + "mlp.fc2.bias"), accumulate=acc)
+        del dy8, dyT8
+        df1 = O.quick_gelu_bwd(f1, da)
+        df18, df1T8 = O.quant_fp8_both(df1)
+        dh2 = O.gemm_fp8(df18, Q["w1T"], out_dtype=dt)
+        self._wgrad_fp8(df1T8, h2, s_h2, A.gview(p + "mlp.fc1.weight"), fresh)
+        O.colsum(df1, A.gview(p + "mlp.fc1.bias"), accumulate=acc)
+        del df18, df1T8
+        dx2 = O.layernorm_bwd(x2, W.ln2w, dh2, eps, dx=dy, accumulate_dx=True, dw_out=A.gview(p + "layer_norm2.weight"),
+                              db_out=A.gview(p + "layer_norm2.bias"), accumulate=acc)
+        dx28, dx2T8 = O.quant_fp8_both(dx2)
+        do = O.gemm_fp8(dx28, Q["woT"], out_dtype=dt)
+        self._wgrad_fp8(dx2T8, o, s_o, A.gview(p + "self_attn.out_proj.weight"), fresh)
+        O.colsum(dx2, A.gview(p + "self_attn.out_proj.bias"), accumulate=acc)
+        del dx28, dx2T8
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
+        O.attn_bwd2(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
+        dqkv8, dqkvT8 = O.quant_fp8_both(dqkv)
+        dh1 = O.gemm_fp8(dqkv8, Q["wqkvT"], out_dtype=dt)
+        self._wgrad_fp8(dqkvT8, h1, s_h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd)), fresh)
+        O.colsum(dqkv, A.gspan(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,)), accumulate=acc)
+        dx = O.layernorm_bwd(x, W.ln1w, dh1, eps, dx=dx2, accumulate_dx=True, dw_out=A.gview(p + "layer_norm1.weight"),
+                             db_out=A.gview(p + "layer_norm1.bias"), accumulate=acc)
+        self._ready(W.names)
+        return dx
+
     def tower(self, images, ctx=None):
         """list of [n_i,3,H,W] -> x [Nimg*(G2+1), vd] = hidden_states[select_layer] (CLS rows kept in place)."""
         m = self.model
@@ -329,11 +417,18 @@ class HipEngine:
             x = O.convert(x32, torch.empty_like(x))  # hidden_states[select_layer] as the projector's 16-bit GEMM operand
             del x32
             L = 0
+        fp8_tower = bool(ctx is not None and ctx.get("fp8_train") and self.fp8_tower and not self.fp32_residual and vd % 128 == 0 and
+                         vc.intermediate_size % 128 == 0)
         for i in range(L):
             if train_tower:
                 xs.append(x)
-            x, sv = self._vit_layer_fwd(self.vit[i], x, N, S, vc, keep=train_tower and self.save_activations)
+            if fp8_tower:
+                x, sv = self._vit_layer_fwd_fp8(self.vit[i], i, x, N, S, vc, keep=train_tower and self.save_activations)
+            else:
+                x, sv = self._vit_layer_fwd(self.vit[i], x, N, S, vc, keep=train_tower and self.save_activations)
             saves.append(sv)
+        if ctx is not None:
+            ctx["fp8_tower"] = fp8_tower
         if ctx is not None:
             ctx.update(vit_cols=cols if train_tower else None, vit_x0=x0 if train_tower else None, vit_xs=xs, vit_saves=saves,
                        vit_N=N, vit_S=S, vit_Kpad=Kpad)
@@ -347,7 +442,10 @@ class HipEngine:
         N, S = ctx["vit_N"], ctx["vit_S"]
         L = tower.layers_used
         for i in reversed(range(L)):
-            dx = self._vit_layer_bwd(self.vit[i], ctx["vit_xs"][i], dx, N, S, vc, ctx["vit_saves"][i], fresh)
+            if ctx.get("fp8_tower"):
+                dx = self._vit_layer_bwd_fp8(self.vit[i], i, ctx["vit_xs"][i], dx, N, S, vc, ctx["vit_saves"][i], fresh)
+            else:
+                dx = self._vit_layer_bwd(self.vit[i], ctx["vit_xs"][i], dx, N, S, vc, ctx["vit_saves"][i], fresh)
             ctx["vit_xs"][i] = None
             ctx["vit_saves"][i] = None
         acc = not fresh
@@ -550,7 +648,8 @@ class HipEngine:
     # e4m3 operands (include/merlin_hip.h, "fp8 TRAINING step"): activations / gradients are quantised dynamically per row
     # (per token for forward and dgrad, per feature - on the transposed copy - for wgrad), weights per output channel (W8)
     # and per input channel (WT8 = rowquant(W^T)), re-quantised once per weight version.  Residual stream, norms, RoPE,
-    # attention, SwiGLU, the CLIP tower, lm_head + CE and all gradient accumulators stay 16-bit / fp32 as in the bf16 step.
+    # attention, SwiGLU, CE and all gradient accumulators stay 16-bit / fp32 as in the bf16 step; lm_head (fp8_head_weights) and the
+    # CLIP tower's Linears (_vit_layer_fwd_fp8) join the decoder's on the fp8 MFMA.
     def fp8_train_weights(self, li):
         def make():
             out = []
@@ -561,6 +660,17 @@ class HipEngine:
                                 wdT=O.quant_fp8_rows_t_e4(W.wd)))
             return self._drop_zero_exponents(out)
         return self._derive("fp8_train_weights", make)[li]
+
+    def fp8_head_weights(self):
+        """lm_head.weight [V, d] for the fp8 training step: per-output-channel copy (logits) and the copy of its transpose (dgrad)."""
+        def make():
+            cfg = self.model.config
+            V, d = cfg.vocab_size, cfg.hidden_size
+            wlm = self.arena.view("lm_head.weight", numel=_ru(V, 64) * d, shape=(_ru(V, 64), d))  # incl. the zero pad rows
+            # (the transposed copy is quantised per input channel only: its rows are the whole vocabulary long, beyond what the
+            #  block-exponent image of the 8-wave kernel holds)
+            return self._drop_zero_exponents([dict(w=O.quant_fp8_rows_e4(wlm), wT=O.quant_fp8_rows_t(wlm))])[0]
+        return self._derive("fp8_head_weights", make)
 
     @staticmethod
     def _drop_zero_exponents(layers):
@@ -760,7 +870,7 @@ class HipEngine:
         B, S = (input_ids.shape if input_ids is not None else inputs_embeds.shape[:2])
         T = B * S
         d = cfg.hidden_size
-        ctx = {"B": B, "S": S, "want_grad": want_grad}
+        ctx = {"B": B, "S": S, "want_grad": want_grad, "fp8_train": fp8 == "train"}
         ctx["train_tower"] = bool(want_grad and tower is not None and not tower.freeze_vision_tower and
                                   any(p.requires_grad for p in tower.parameters()))
         self._rope_table(S, dev)
@@ -799,7 +909,6 @@ class HipEngine:
         # ---- decoder ----
         xs, saves = [], []
         fp8_train = fp8 == "train"
-        ctx["fp8_train"] = fp8_train
         if fp8 and (d % 128 or cfg.intermediate_size % 128):
             raise RuntimeError("the fp8 GEMM path needs hidden and intermediate sizes that are multiples of 128")
         if fp8 and not fp8_train:
@@ -850,7 +959,18 @@ class HipEngine:
             last = (lens.to(torch.int64) - 1) if lens is not None else torch.full((B,), S - 1, dtype=torch.int64, device=dev)
             rows = O.gather_rows(hn, torch.arange(B, device=dev) * S + last.clamp_min(0))
             return None, O.gemv(rows, wlm, out_f32=True, n=V), ctx
-        logits = O.gemm_nt(hn, wlm, out_f32=True)  # [T, Vpad] fp32
+        # fp8 training step: the head's three GEMMs run on the scaled-fp8 MFMA too (BASELINE cfg 5: every Linear) when the geometry
+        # allows it (contractions over d, V and T in whole 128-blocks); the logits stay fp32
+        fp8_head = bool(fp8_train and self.fp8_head and not last_only and d % 128 == 0)
+        ctx["fp8_head"] = fp8_head
+        self.last_fp8 = dict(decoder=bool(fp8_train), tower=bool(ctx.get("fp8_tower")), head=fp8_head)  # which parts of this forward ran on fp8 (tests, bench)
+        if fp8_head:
+            hn8 = O.quant_fp8_rows(hn)
+            logits = O.gemm_fp8(hn8, self.fp8_head_weights()["w"], out=torch.empty(T, Vpad, dtype=torch.float32, device=dev), dt16=dt)
+            ctx["hn_scales"] = hn8[1] if want_grad else None
+            del hn8
+        else:
+            logits = O.gemm_nt(hn, wlm, out_f32=True)  # [T, Vpad] fp32
         loss = None
         if labels is not None:
             row_loss, lse, out = O.ce_fwd(logits, labels, V)
@@ -882,8 +1002,18 @@ class HipEngine:
         dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
         ctx["logits"] = None
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
-        dhn = O.gemm_nt(dlogits, wlm, b_t=True)  # [T, d]; B = W^T [d, Vpad]
-        if self._trainable("lm_head.weight"):
+        if ctx.get("fp8_head"):
+            train_head = self._trainable("lm_head.weight")
+            V128 = _ru(Vpad, 128)  # the dgrad contracts over the (padded) vocabulary in whole 128-blocks: zero columns behind Vpad
+            dl8, dlT8 = O.quant_fp8_both(dlogits, c_pad=V128) if train_head else (O.quant_fp8_rows(dlogits, k_pad=V128), None)
+            dhn = O.gemm_fp8(dl8, self.fp8_head_weights()["wT"], out_dtype=dt)  # [T, d]
+            if train_head:  # rows [V, Vpad) of the padded gradient block receive exact zeros (dlogits' pad columns are zero)
+                off = A.offset["lm_head.weight"]
+                self._wgrad_fp8(dlT8, ctx["hn"], ctx["hn_scales"], A.gflat[off: off + Vpad * d].view(Vpad, d), fresh)
+            del dl8, dlT8
+        else:
+            dhn = O.gemm_nt(dlogits, wlm, b_t=True)  # [T, d]; B = W^T [d, Vpad]
+        if self._trainable("lm_head.weight") and not ctx.get("fp8_head"):
             if T % 64 == 0:
                 # rows [V, Vpad) of the padded gradient block receive exact zeros (dlogits' pad columns are zero)
                 off = A.offset["lm_head.weight"]

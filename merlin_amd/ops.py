@@ -396,12 +396,12 @@ def gemm_swiglu_bwd(dy, wd, gu):
     return dgu
 
 
-def quant_fp8_rows(x):
-    """x [R, K] (16-bit) -> (q uint8 [R, K] OCP e4m3, scales fp32 [R]): one scale per row."""
+def quant_fp8_rows(x, k_pad=None):
+    """x [R, K] (16-bit) -> (q uint8 [R, K] OCP e4m3, scales fp32 [R]): one scale per row.  k_pad > K: q is [R, k_pad], zero behind K."""
     R, K = x.shape
-    q = torch.empty(R, K, dtype=torch.uint8, device=x.device)
+    q = torch.zeros(R, k_pad, dtype=torch.uint8, device=x.device) if (k_pad is not None and k_pad > K) else torch.empty(R, K, dtype=torch.uint8, device=x.device)
     sc = torch.empty(R, dtype=torch.float32, device=x.device)
-    L.check(L.lib().mh_quant_fp8_rows(p(x), i64(_rowmajor(x)), p(q), i64(K), p(sc), i32(R), i32(K), i32(dt_of(x)), _stream()), "mh_quant_fp8_rows")
+    L.check(L.lib().mh_quant_fp8_rows(p(x), i64(_rowmajor(x)), p(q), i64(q.stride(0)), p(sc), i32(R), i32(K), i32(dt_of(x)), _stream()), "mh_quant_fp8_rows")
     return q, sc
 
 
@@ -463,12 +463,16 @@ def quant_fp8_rows_t(x):
 _both_ws = {}
 
 
-def quant_fp8_both(x):
+def quant_fp8_both(x, c_pad=None):
     """x [R, C] (16-bit) -> ((q [R, C], s_row [R]), (qt [C, round_up(R, 128)], s_col [C])): the row-quantised operand (dgrad) and the
-    transposed, per-feature-scaled operand (wgrad) of a gradient tensor from two reads of it."""
+    transposed, per-feature-scaled operand (wgrad) of a gradient tensor from two reads of it.  c_pad > C: q is [R, c_pad] with zero
+    columns behind C (a contraction length that is not a whole number of 128-blocks: the vocabulary)."""
     R, C_ = x.shape
     Rp = round_up(R, 128)
-    q = torch.empty(R, C_, dtype=torch.uint8, device=x.device)
+    if c_pad is not None and c_pad > C_:
+        q = torch.zeros(R, c_pad, dtype=torch.uint8, device=x.device)
+    else:
+        q = torch.empty(R, C_, dtype=torch.uint8, device=x.device)
     sr = torch.empty(R, dtype=torch.float32, device=x.device)
     qt = torch.empty(C_, Rp, dtype=torch.uint8, device=x.device)
     sc = torch.empty(C_, dtype=torch.float32, device=x.device)
@@ -477,7 +481,7 @@ def quant_fp8_both(x):
         if len(_both_ws) > 16:
             _both_ws.clear()
         ws = _both_ws[(x.device, R + C_)] = torch.empty(R + C_, dtype=torch.int32, device=x.device)
-    L.check(L.lib().mh_quant_fp8_rows_and_t(p(x), i64(_rowmajor(x)), p(q), i64(C_), p(sr), p(qt), i64(Rp), p(sc), p(ws), i32(R), i32(C_),
+    L.check(L.lib().mh_quant_fp8_rows_and_t(p(x), i64(_rowmajor(x)), p(q), i64(q.stride(0)), p(sr), p(qt), i64(Rp), p(sc), p(ws), i32(R), i32(C_),
                                             i32(dt_of(x)), _stream()), "mh_quant_fp8_rows_and_t")
     return (q, sr), (qt, sc)
 
@@ -507,8 +511,9 @@ def gemm_fp8_swiglu_bwd(dy8, wdt8, gu):
     return dgu
 
 
-def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None, accum=False):
-    """out[M, N] = (sa qa) @ (sb qb)^T on the scaled-fp8 MFMA; a8 = (qa [M, K] uint8, sa [M]), b8 = (qb [N, K], sb [N])."""
+def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, act=None, accum=False, dt16=torch.bfloat16):
+    """out[M, N] = (sa qa) @ (sb qb)^T on the scaled-fp8 MFMA; a8 = (qa [M, K] uint8, sa [M]), b8 = (qb [N, K], sb [N]).
+    A float32 `out` / out_dtype selects the fp32 store phase (the lm_head logits); dt16 is then the type of bias / resid."""
     (qa, sa), (qb, sb, eb) = a8[:2], _b3(b8)
     M, K = qa.shape
     N = qb.shape[0]
@@ -526,9 +531,13 @@ def gemm_fp8(a8, b8, out_dtype=torch.bfloat16, out=None, bias=None, resid=None, 
     if accum:
         assert out is not None
         epi |= EPI_ACCUM
+    dt = dt_of(out)
+    if out.dtype == torch.float32:
+        epi |= EPI_OUT_F32
+        dt = dt_of(dt16)
     with _timed("gemm_fp8", 2.0 * M * N * K):
         L.check(L.lib().mh_gemm_fp8(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(out), i64(_rowmajor(out)), p(bias),
-                                    p(resid), i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(out)), i32(epi), _stream()), "mh_gemm_fp8")
+                                    p(resid), i64(ldr), i32(M), i32(N), i32(K), i32(dt), i32(epi), _stream()), "mh_gemm_fp8")
     return out
 
 

@@ -8,10 +8,15 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.
 f=$(find /tmp/kt -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $f > $R/gpurun_out/r03_step_cfg3_kernel_stats_$TAG.txt 2>&1 || ls -R /tmp/kt | head
 tail -1 /tmp/kt.log > $R/gpurun_out/r03_step_cfg3_bench_under_rocprof_$TAG.json
-bash $R/tools/pmc_step_traffic.sh r03_gemm_traffic.json > /dev/null 2>&1
+rm -rf /tmp/kt5
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o r -- python $R/bench.py --config cfg5 --steps 3 --warmup 3 --no-cpu-baseline > /tmp/kt5.log 2>&1
+f5=$(find /tmp/kt5 -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $f5 > $R/gpurun_out/r03_step_cfg5_fp8_kernel_stats_$TAG.txt 2>&1 || ls -R /tmp/kt5 | head
+tail -1 /tmp/kt5.log > $R/gpurun_out/r03_step_cfg5_bench_under_rocprof_$TAG.json
+if [ "${SKIP_PMC:-0}" != "1" ]; then bash $R/tools/pmc_step_traffic.sh r03_gemm_traffic.json > /dev/null 2>&1; fi
 cd $R
 python bench.py --steps 4 --warmup 2 --force-dp --no-cpu-baseline --no-extras > gpurun_out/bench_r03_force_dp_$TAG.json 2> gpurun_out/bench_r03_force_dp_$TAG.err
-cp gpurun_out/r03_gemm_traffic.json profiles/r03_gemm_traffic.json
+if [ "${SKIP_PMC:-0}" != "1" ]; then cp gpurun_out/r03_gemm_traffic.json profiles/r03_gemm_traffic.json; fi
 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_r03_default_$TAG.json 2> /dev/null
 tail -c 1500 gpurun_out/bench_r03_force_dp_$TAG.json; echo; head -30 gpurun_out/r03_step_cfg3_kernel_stats_$TAG.txt; cat gpurun_out/r03_gemm_traffic.json; python -c "
 import json; d=json.load(open('gpurun_out/bench_r03_default_$TAG.json')); print(d['ms_per_step'], d['value'], d['roofline'])"

@@ -270,6 +270,12 @@ def main(argv=None):
         from merlin_amd import ops as _O
         _O.gemm_force_kernel(int(os.environ["MH_GEMM_FORCE"]))
 
+    # The result line must be the only thing on stdout: RCCL prints a version banner there (C stdio, flushed at exit, after our line) and
+    # so might any other library.  Keep the real stdout aside for the one JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -557,7 +563,7 @@ def main(argv=None):
             line["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # the baseline leg must never take the GPU number down
             line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
-    print(json.dumps(line), flush=True)
+    os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dp:
         dist.destroy_process_group()
 

@@ -1013,3 +1013,24 @@ def test_attention_forward_pingpong_form_matches(ops, dtype, B, S, H, causal, ra
     assert relerr(o1[:n, :D], ref) < 4 * EPS16[dtype]
     if n < S:
         assert float(o1[n:S, :D].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d,ld", [(27696, 1024, 1024), (1000, 3072, 3072), (777, 1024, 3072), (77, 40, 40), (5, 4096, 4096), (48, 8 * 577, 8 * 577), (300, 264, 272)])
+def test_colsum_matches_torch(ops, dtype, rows, d, ld):
+    """Bias / position-embedding gradients: column sums of a (possibly strided) 16-bit matrix, fresh and accumulating; the 16-byte-per-lane
+    form (d % 8 == 0, aligned rows) and the scalar fallback."""
+    full = rnd(rows, ld, dtype=dtype, seed=rows + d)
+    x = full[:, :d]
+    ref = x.float().sum(0)
+    out = torch.zeros(d, dtype=dtype, device=dev())
+    ops.colsum(x, out)
+    tol = 2 * EPS16[dtype] * float(x.float().abs().sum(0).max()) + 1e-6
+    assert float((out.float() - ref).abs().max()) <= tol
+    prev = rnd(d, dtype=dtype, seed=7)
+    out2 = prev.clone()
+    ops.colsum(x, out2, accumulate=True)
+    assert float((out2.float() - (ref + prev.float())).abs().max()) <= tol + 2 * EPS16[dtype] * float(prev.float().abs().max())
+    out3 = torch.zeros(d, dtype=dtype, device=dev())
+    ops.colsum(x, out3)
+    assert torch.equal(out, out3)  # deterministic

@@ -401,9 +401,12 @@ def main(argv=None):
                     return model(**dbatch).loss
             return train_step(dbatch)
 
+    loss_first = None
     for wi in range(args.warmup):
         tw = time.perf_counter()
         loss = step()
+        if wi == 0:
+            loss_first = loss.detach().clone()  # read back after the timed region
         if os.environ.get("MH_BENCH_PER_STEP"):  # warm-up profile (stderr): how many steps until the step time is flat
             dev_sync()
             print(f"[bench] warm-up step {wi}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
@@ -494,7 +497,9 @@ def main(argv=None):
                   "bf16 (fp32 residual streams)" if args.fp32_residual else "bf16"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
-                   "step": step_desc, "loss": round(loss_val, 4)},
+                   "step": step_desc, "loss": round(loss_val, 4),
+                   # the same batch every step: a real optimizer step shows as a falling loss (first warm-up step -> last timed step)
+                   "loss_first_warmup_step": (round(float(loss_first), 4) if loss_first is not None else None)},
         "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
         "peak_hbm_gb": round(peak_gb, 1),
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -141,6 +141,14 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
                    void* stream);
 
+/* Split-K with mh_gemm's full epilogue (bias, quick-GELU, residual, accumulate, fp32 store - applied by the fixed-order reduce pass
+ * exactly as the one-pass store phase applies them): for products with few output tiles and a long contraction, e.g. the o / down
+ * projections and the dgrads of a 613-token sequence (48 tiles for 256 CUs).  ws: splits * M * N floats; N % 4 == 0, ldc % 4 == 0;
+ * splits from mh_gemm_splitk_max (1 = the plain mh_gemm call).  Replaces the same nn.Linear calls as mh_gemm. */
+int mh_gemm_splitk_epi(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C, int64_t ldc,
+                       const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt, int epilogue, int splits, float* ws,
+                       void* stream);
+
 /* Kernel selection override for tests / A-B benchmarks: 0 = auto (256x256 tiles when they fill the chip, else 128x128; among the
  * 256x256 kernels the 4-wave form where mh_gemm_w4_policy says so), 128 = the 128x128 kernel, 256 = the 8-wave 256x256 kernel,
  * 4 = the 4-wave 256x256 kernel (128x128 outputs per wave, csrc/gemm_w4.hip) wherever it can run. */

@@ -188,6 +188,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
   }
 }
 
+// the same with the GEMM's own epilogue (bias, quick-GELU, residual, accumulate, fp32 store: epi_store4) behind the sum: split-K for
+// the skinny forward / dgrad products of short sequences (mh_gemm_splitk_epi)
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_epi_k(const float* __restrict__ ws, int splits, int64_t split_stride, GemmArgs g) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // quad index over M * N/4
+  const int nq = g.N >> 2;
+  if (q >= (int64_t)g.M * nq) return;
+  const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+  float4 s = *(const float4*)(ws + (int64_t)m * g.N + n);
+  for (int i = 1; i < splits; ++i) {
+    const float4 t = *(const float4*)(ws + i * split_stride + (int64_t)m * g.N + n);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  epi_store4<DT>(g, m, n, s.x, s.y, s.z, s.w);
+}
+
 struct RopeSpec {
   const float* tab = nullptr; int S = 0, D = 0, cols = 0;
   int sw_mode = 0, sw_ff = 0; void* sw_out = nullptr; const void* sw_in = nullptr; int64_t sw_ldo = 0, sw_ldi = 0;  // fused SwiGLU
@@ -396,6 +412,40 @@ extern "C" int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const 
     hipLaunchKernelGGL(splitk_reduce_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, C, ldc, M, N, out_f32, accumulate);
   else
     hipLaunchKernelGGL(splitk_reduce_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, C, ldc, M, N, out_f32, accumulate);
+  MH_LAUNCH_CHECK();
+}
+
+// Split-K with the full epilogue: `splits` blocks per output tile write fp32 partials to ws (splits * M * N floats), one fixed-order
+// pass sums them and applies bias / quick-GELU / residual / accumulate / the fp32 store exactly as the one-pass kernel's store phase does.
+// For products with few output tiles and a long contraction (a 613-token sequence gives the o / down projections and every dgrad
+// 48 tiles for 256 CUs).  splits from mh_gemm_splitk_max; 1 = the plain call.
+extern "C" int mh_gemm_splitk_epi(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C, int64_t ldc,
+                                  const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt, int epilogue, int splits,
+                                  float* ws, void* stream) {
+  if (splits < 1 || splits > 64) return MH_ERR_ARG;
+  if (splits == 1) return gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, C, ldc, bias, resid, ldr, M, N, K, dt, epilogue, 1, 0, stream);
+  if (!ws || !C || (N & 3) || (ldc & 3)) return MH_ERR_ARG;
+  if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
+  if ((epilogue & MH_EPI_RESIDUAL) && !resid) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const int nk = (K + BK - 1) / BK;
+  if ((int64_t)(splits - 1) * ((nk + splits - 1) / splits) >= nk) return MH_ERR_ARG;  // an empty split
+  const int rc = gemm_impl(A, lda, a_kstrided, B, ldb, b_kstrided, ws, N, nullptr, nullptr, 0, M, N, K, dt, MH_EPI_OUT_F32, splits,
+                           (int64_t)M * N, stream);
+  if (rc != MH_OK) return rc;
+  GemmArgs g{};
+  g.C = C; g.bias = (const uint16_t*)bias; g.resid = (const uint16_t*)resid;
+  g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+  const bool f32out = epilogue & MH_EPI_OUT_F32;
+  g.vec_ok = (ldc % 4 == 0) && ((((uintptr_t)C) & (f32out ? 15u : 7u)) == 0) &&
+             (!(epilogue & MH_EPI_RESIDUAL) || ((ldr % 4 == 0) && ((((uintptr_t)resid) & 7u) == 0))) &&
+             (!(epilogue & MH_EPI_BIAS) || ((((uintptr_t)bias) & 7u) == 0));
+  const int64_t quads = (int64_t)M * (N >> 2);
+  const unsigned grid = (unsigned)((quads + 255) / 256);
+  if (dt == MH_F16)
+    hipLaunchKernelGGL(splitk_reduce_epi_k<MH_F16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, g);
+  else
+    hipLaunchKernelGGL(splitk_reduce_epi_k<MH_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), ws, splits, (int64_t)M * N, g);
   MH_LAUNCH_CHECK();
 }
 

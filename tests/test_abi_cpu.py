@@ -42,3 +42,24 @@ def test_product_never_imports_oracle():
         if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
             bad.append(str(f))
     assert not bad, bad
+
+
+def test_host_side_launch_plans():
+    """Host-only entry points (no launch): the split counts mh_gemm_splitk_max hands the skinny-GEMM path of ops.gemm_nt and the
+    split-KV count of the decode attention."""
+    import ctypes as C
+
+    from merlin_amd import _lib as L
+
+    lib = L.lib()
+    sk = lambda M, N, K: int(lib.mh_gemm_splitk_max(C.c_int(M), C.c_int(N), C.c_int(K)))  # noqa: E731
+    assert sk(613, 4096, 4096) == 5 and sk(613, 4096, 11008) == 5   # o / down projections of one 613-token sequence: 48 tiles
+    assert sk(613, 12288, 4096) == 1 and sk(613, 22016, 4096) == 1   # q|k|v and gate|up fill the chip on their own
+    assert sk(32768, 4096, 4096) == 1                                # the headline shapes never split
+    assert sk(613, 4096, 512) == 1                                   # short contractions are not worth the reduce pass
+    for M, N, K in ((577, 1024, 4096), (40, 4096, 12288), (1000, 1032, 2048)):
+        s = sk(M, N, K)
+        nk = (K + 63) // 64
+        assert 1 < s <= 16 and (s - 1) * ((nk + s - 1) // s) < nk, (M, N, K, s)  # no empty split
+    assert int(lib.mh_attn_decode_splits(C.c_int(1), C.c_int(32), C.c_int(4096))) == 32
+    assert int(lib.mh_attn_decode_splits(C.c_int(8), C.c_int(32), C.c_int(4096))) == 4

@@ -168,8 +168,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg-2 (S=613) row of the N=1 line's `extras`")
     ap.add_argument("--fp8-forward", action="store_true", help="with --fwd-only: decoder Linears on the scaled-fp8 MFMA (e4m3 operands, "
                     "per-row scales); NOT the headline configuration (dtype field says so)")
-    ap.add_argument("--fp32-residual", action="store_true", help="both towers' residual streams in fp32 (engine.fp32_residual): the "
-                    "closer-to-the-reference forward (DESIGN.md, parity table); NOT the headline configuration")
+    ap.add_argument("--fp32-residual", action="store_true", help="(default since round 4, kept for old command lines) both towers' residual "
+                    "streams in fp32 (engine.fp32_residual): the configuration whose parity is quoted")
+    ap.add_argument("--residual-16bit", action="store_true", help="16-bit residual streams (engine.fp32_residual = False: the reference's own "
+                    "bf16 training numerics, -1.4 % step time); NOT the headline configuration")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the model over gloo: exercises the launcher, GradSync, the "
                     "barrier / max-over-ranks timing and the JSON line without a GPU (tests/test_bench_cpu.py); the numbers mean nothing")
     ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the N>1 code path (RCCL process group of one rank, GradSync on its "
@@ -242,21 +244,30 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
+def traffic_summary_path():
+    """The newest per-round PMC summary, profiles/rNN_gemm_traffic.json (tools/pmc_step_traffic.sh writes it)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_traffic.json")))
+    return found[-1] if found else None
+
+
 def read_traffic(args):
     """HBM/fabric traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
     (tools/pmc_step_traffic.sh; PMC collection cannot run inside the timed process).  The committed summary is quoted only when
     it was taken on the kernel sources of THIS build (stamp) and for the default configuration."""
-    if args.config != "cfg3" or args.fwd_only or args.fp8_train or args.recompute or args.dry_run or args.fp32_residual:
+    if args.config != "cfg3" or args.fwd_only or args.fp8_train or args.recompute or args.dry_run or args.residual_16bit:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+    path = traffic_summary_path()
+    name = "profiles/" + os.path.basename(path) if path else "profiles/r*_gemm_traffic.json"
     try:
         with open(path) as f:
             t = json.load(f)
     except Exception:
-        return None, "no PMC summary for this round (profiles/r03_gemm_traffic.json)"
+        return None, f"no PMC summary ({name})"
     if t.get("kernel_source_stamp") != kernel_source_stamp():
-        return None, f"profiles/r03_gemm_traffic.json was taken on other kernel sources (stamp {t.get('kernel_source_stamp')}): not quoted"
-    return round(t["traffic_bytes_per_launch"] / 1e9, 3), "GB per GEMM kernel launch (L2<->fabric incl. Infinity-Cache hits, PMC: profiles/r03_gemm_traffic.json: " \
+        return None, f"{name} was taken on other kernel sources (stamp {t.get('kernel_source_stamp')}): not quoted"
+    return round(t["traffic_bytes_per_launch"] / 1e9, 3), f"GB per GEMM kernel launch (L2<->fabric incl. Infinity-Cache hits, PMC: {name}: " \
         f"{t.get('traffic_bytes_per_step', 0) / 1e12:.2f} TB per step = {t.get('traffic_over_algorithmic', 0):.2f} x the algorithmic " \
         f"{t.get('algorithmic_bytes_per_step', 0) / 1e12:.2f} TB; a bench `launch` below is one GEMM call = 1-3 kernel launches)"
 
@@ -342,7 +353,7 @@ def main(argv=None):
         model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
         eng = model.engine
         eng.save_activations = not args.recompute
-        eng.fp32_residual = bool(args.fp32_residual)
+        eng.fp32_residual = not args.residual_16bit
         if args.fp8_forward:
             assert args.fwd_only, "--fp8-forward is forward-only"
             model.fp8_forward = True
@@ -494,7 +505,7 @@ def main(argv=None):
         "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("cpu-fp32 (dry run)" if dry else "fp8-e4m3 decoder GEMMs (bf16 elsewhere)" if args.fp8_forward else
                   "fp8-e4m3 Linear GEMMs (decoder, lm_head) fwd+dgrad+wgrad, per-row scales (bf16 residual stream / attention / norms / CLIP tower, fp32 accumulate)" if args.fp8_train else
-                  "bf16 (fp32 residual streams)" if args.fp32_residual else "bf16"),
+                  "bf16 (16-bit residual streams)" if args.residual_16bit else "bf16 (fp32 residual streams, fp32 accumulate)"),
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
                    "step": step_desc, "loss": round(loss_val, 4),
@@ -511,7 +522,7 @@ def main(argv=None):
     }
     if traffic:
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")) as f:
+            with open(traffic_summary_path()) as f:
                 line["roofline"]["traffic_over_algorithmic"] = round(json.load(f)["traffic_over_algorithmic"], 2)
         except Exception:
             pass
@@ -523,6 +534,14 @@ def main(argv=None):
         line["comm_ms_exposed"] = round(max(r[2] for r in per_rank), 2)    # per step: compute stream idle at the end of backward
         line["comm_collectives_per_step"] = comm["collectives"] // max(1, args.steps)
         line["comm_gb_per_step"] = round(comm["bytes"] / max(1, args.steps) / 1e9, 3)
+        nb = line["comm_collectives_per_step"]
+        if comm.get("each_ms") and nb and len(comm["each_ms"]) == nb * args.steps:  # rank 0's buckets, averaged over the timed steps, in issue order
+            line["comm_per_bucket_ms"] = [round(sum(comm["each_ms"][i::nb]) / args.steps, 3) for i in range(nb)]
+            line["comm_bucket_mb"] = [round(b / 1e6, 1) for b in comm.get("bucket_bytes", [])]
+        # what RCCL was told (its own choice - ring / tree, LL / LL128 / simple - is per collective size unless pinned here)
+        line["rccl_env"] = {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                        "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")}
+        line["gemm_persistent"] = os.environ.get("MH_GEMM_PERSISTENT", "1") != "0"
         line["per_rank"] = [{"rank": i, "peak_hbm_gb": r[0], "comm_ms_total": r[1], "comm_ms_exposed": r[2]} for i, r in enumerate(per_rank)]
         line["recompute_fallback"] = recompute_fallback
         line.update(hbm_info)

@@ -66,10 +66,9 @@ class GradSync:
 
     # ---- engine callbacks -----------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
-        """Zero (or detach) the model's gradients and forget that they were reduced.  `optimizer.zero_grad(set_to_none=False)`
-        / `model.zero_grad(set_to_none=False)` leave `.grad` attached, which the arena cannot tell from accumulated values;
-        an optimizer step in between (the weights changed since the reduce) is recognised on its own, this call covers the
-        rest (e.g. a skipped step after an overflow)."""
+        """Zero (or detach) the model's gradients and forget that they were reduced.  (`optimizer.zero_grad(set_to_none=False)` /
+        `model.zero_grad(set_to_none=False)` leave `.grad` attached; the next backward then verifies on the device that the arena
+        really holds zeros - this call saves that check.)"""
         for p in self.engine.arena.params.values():
             if p.grad is not None:
                 if set_to_none:
@@ -78,14 +77,33 @@ class GradSync:
                     p.grad.zero_()
         self._reduced = False
 
+    def _grads_all_zero(self) -> bool:
+        """True when the whole gradient arena holds zeros (one reduction + a host read: only taken on the rare path below)."""
+        g = self.engine.arena.gflat
+        if g is None:
+            return True
+        if g.is_cuda:
+            from . import ops as O
+
+            out = torch.zeros(1, dtype=torch.float32, device=g.device)
+            O.sumsq(g, out)
+            return float(out.item()) == 0.0  # (NaN / Inf compare unequal: not zero)
+        return not bool(torch.count_nonzero(g))
+
     def _on_begin(self, fresh: bool):
-        if fresh or (self._reduced and self._reduced_at != self.engine.weight_version):
-            # fresh gradients, or an optimizer stepped since the reduce (FusedAdamW bumps weight_version; a stock torch optimizer
-            # is seen through the parameters' version counters at the next forward): the window that was reduced is over
+        if fresh:
             self._reduced = False
         elif self._reduced and self.active:
-            raise RuntimeError("merlin_amd.dp: this backward accumulates onto gradients that were already all-reduced; run all "
-                               "but the last micro-step of an accumulation window under GradSync.no_sync() (or zero_grad first)")
+            # Attached gradients that were already all-reduced.  Accumulating onto them is only sound when they hold ZEROS
+            # (optimizer.zero_grad(set_to_none=False) / model.zero_grad(set_to_none=False) after a step: `.grad` stays attached, the
+            # arena cannot report `fresh`): that is checked on the device - a changed weight version alone is not enough, an
+            # optimizer step WITHOUT zero_grad (or any in-place parameter edit) also bumps it and would otherwise let this backward
+            # add local gradients onto world-summed ones and reduce them a second time (world * G_old + sum g_new).
+            if self._grads_all_zero():
+                self._reduced = False
+            else:
+                raise RuntimeError("merlin_amd.dp: this backward accumulates onto gradients that were already all-reduced; run all "
+                                   "but the last micro-step of an accumulation window under GradSync.no_sync() (or zero_grad first)")
         if self._sync:
             self.order = []
 
@@ -147,9 +165,11 @@ class GradSync:
     def pop_timing(self):
         """Call after a device synchronize: {comm_ms_total (sum over collectives, on the communication stream), comm_ms_exposed
         (time the compute stream waited at the end of backward), collectives, bytes} since the last call."""
-        total = self._t_host[0] + sum(a.elapsed_time(b) for a, b in self._t_coll)
+        each = [a.elapsed_time(b) for a, b in self._t_coll]  # per collective, in issue order (steps x buckets)
+        total = self._t_host[0] + sum(each)
         exposed = self._t_host[1] + sum(a.elapsed_time(b) for a, b in self._t_wait)
-        out = dict(comm_ms_total=total, comm_ms_exposed=exposed, collectives=self.n_collectives, bytes=self.bytes)
+        out = dict(comm_ms_total=total, comm_ms_exposed=exposed, collectives=self.n_collectives, bytes=self.bytes, each_ms=each,
+                   bucket_bytes=[n * self.engine.arena.gflat.element_size() for _, n in self.order])
         self._t_coll, self._t_wait, self._t_host = [], [], [0.0, 0.0]
         self.n_collectives = self.bytes = 0
         return out

@@ -185,7 +185,9 @@ def _sample_cached(model, input_ids, images, attention_mask, max_len, eos_ids, p
     # right-padded prompts (ones then zeros; an extension - HF wants left padding): each row continues from its own length.
     # Anything else (HF's left padding, holes) follows transformers: new tokens are appended after the padded prompt, keys are the
     # valid positions only, rotary positions stay absolute (the engine's unpad / pad attention path + compacted KV cache).
-    padded = am is not None and not bool(am.all()) and bool((am[:, 1:] <= am[:, :-1]).all())
+    # ONE decision, the engine's (made on the device from the mask in forward(): a right-padded prefix keeps the lens fast path, anything
+    # else - or engine.force_unpad - compacts the valid keys and sets cache.rpos): generate() follows it instead of classifying again
+    padded = am is not None and not bool(am.all()) and cache.rpos is None
     ids = input_ids.to(dev)
     lens = am.sum(dim=1) if padded else None
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)

@@ -35,6 +35,42 @@ import torch.nn.functional as F
 
 IGNORE_INDEX = -100  # mmgpt/utils/constants.py:7
 
+# ---- storage-rounding model (tests/test_parity_floor_gpu.py, tools/measure_parity.py) -------------------------------------------------
+# None (default): the plain fp32 restatement, bit-identical to the reference goldens.  `rounding(dtype, stream=...)` makes this SAME
+# fp32 forward round, to `dtype`, every tensor that a 16-bit-operand matrix unit has to take as an input - the activation operand of
+# every Linear (weights from merlin_amd/weights.py are exactly representable), the rotated q / k, v and the softmax probabilities of
+# both attentions - and, with stream=True, the residual streams after every add as well.  Accumulation, norms, softmax, RoPE, SwiGLU
+# stay fp32.  The logits error of that run against the reference golden is the FLOOR of any single-pass 16-bit-operand implementation:
+# what the HIP path's own error is held against.
+_ROUND = None
+
+
+class rounding:
+    def __init__(self, dtype, stream=False):
+        self.cfg = (dtype, bool(stream))
+
+    def __enter__(self):
+        global _ROUND
+        self.old, _ROUND = _ROUND, self.cfg
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = self.old
+
+
+def _q(x):
+    """a matrix-unit operand"""
+    return x if _ROUND is None else x.to(_ROUND[0]).to(x.dtype)
+
+
+def _qs(x):
+    """a residual stream"""
+    return x if (_ROUND is None or not _ROUND[1]) else x.to(_ROUND[0]).to(x.dtype)
+
+
+def _linear(x, w, b=None):
+    return F.linear(_q(x), w, b)
+
 VT = "model.vision_tower.vision_tower.vision_model."
 PJ = "model.projector.projector."
 
@@ -135,30 +171,30 @@ def clip_tower_forward(P: dict, cfg: OracleConfig, pixels: torch.Tensor) -> torc
     N = pixels.shape[0]
     vd, nh = cfg.v_hidden_size, cfg.v_num_attention_heads
     hd = vd // nh
-    x = F.conv2d(pixels, P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size)
+    x = F.conv2d(_q(pixels), P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size)
     x = x.flatten(2).transpose(1, 2)  # [N, grid^2, vd]
     cls = P[VT + "embeddings.class_embedding"].expand(N, 1, -1)
     x = torch.cat([cls, x], dim=1) + P[VT + "embeddings.position_embedding.weight"][None]
-    x = F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps)
+    x = _qs(F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps))
     for i in range(cfg.v_layers_used):
         p = VT + f"encoder.layers.{i}."
         r = x
         h = F.layer_norm(x, (vd,), P[p + "layer_norm1.weight"], P[p + "layer_norm1.bias"], cfg.v_layer_norm_eps)
-        q = F.linear(h, P[p + "self_attn.q_proj.weight"], P[p + "self_attn.q_proj.bias"])
-        k = F.linear(h, P[p + "self_attn.k_proj.weight"], P[p + "self_attn.k_proj.bias"])
-        v = F.linear(h, P[p + "self_attn.v_proj.weight"], P[p + "self_attn.v_proj.bias"])
+        q = _linear(h, P[p + "self_attn.q_proj.weight"], P[p + "self_attn.q_proj.bias"])
+        k = _linear(h, P[p + "self_attn.k_proj.weight"], P[p + "self_attn.k_proj.bias"])
+        v = _linear(h, P[p + "self_attn.v_proj.weight"], P[p + "self_attn.v_proj.bias"])
         S = x.shape[1]
-        q = q.view(N, S, nh, hd).transpose(1, 2)
-        k = k.view(N, S, nh, hd).transpose(1, 2)
-        v = v.view(N, S, nh, hd).transpose(1, 2)
+        q = _q(q).view(N, S, nh, hd).transpose(1, 2)
+        k = _q(k).view(N, S, nh, hd).transpose(1, 2)
+        v = _q(v).view(N, S, nh, hd).transpose(1, 2)
         att = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
-        o = (att @ v).transpose(1, 2).reshape(N, S, vd)
-        x = r + F.linear(o, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"])
+        o = (_q(att) @ v).transpose(1, 2).reshape(N, S, vd)
+        x = _qs(r + _linear(o, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"]))
         r = x
         h = F.layer_norm(x, (vd,), P[p + "layer_norm2.weight"], P[p + "layer_norm2.bias"], cfg.v_layer_norm_eps)
-        h = F.linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])
+        h = _linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])
         h = h * torch.sigmoid(1.702 * h)  # quick_gelu
-        x = r + F.linear(h, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"])
+        x = _qs(r + _linear(h, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"]))
     if cfg.vision_select_feature == "patch":  # clip_encoder.py:66-67
         x = x[:, 1:]
     return x
@@ -167,11 +203,11 @@ def clip_tower_forward(P: dict, cfg: OracleConfig, pixels: torch.Tensor) -> torc
 def projector_forward(P: dict, cfg: OracleConfig, feats: torch.Tensor) -> torch.Tensor:
     """[n, grid^2, vd] -> [n, P, d].  mlp_projector.py:19-23 / conv_projector.py:23-39."""
     if cfg.projector == "mlp":
-        return F.linear(feats, P[PJ + "weight"], P[PJ + "bias"])
+        return _linear(feats, P[PJ + "weight"], P[PJ + "bias"])
     B, Pn, C = feats.shape
     HW = int(math.sqrt(Pn))
     f = feats.permute(0, 2, 1).reshape(B, C, HW, HW)
-    y = F.conv2d(f, P[PJ + "weight"], P[PJ + "bias"], stride=cfg.conv_stride, padding=1)
+    y = F.conv2d(_q(f), P[PJ + "weight"], P[PJ + "bias"], stride=cfg.conv_stride, padding=1)
     return y.reshape(B, y.shape[1], -1).permute(0, 2, 1)
 
 
@@ -227,15 +263,15 @@ def rotate_half(x):
 def llama_attention(P, cfg, prefix, h, cos, sin, add_mask):
     B, S, d = h.shape
     nh, hd = cfg.num_attention_heads, cfg.head_dim
-    q = F.linear(h, P[prefix + "q_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
-    k = F.linear(h, P[prefix + "k_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
-    v = F.linear(h, P[prefix + "v_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
-    q = q * cos + rotate_half(q) * sin
-    k = k * cos + rotate_half(k) * sin
+    q = _linear(h, P[prefix + "q_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
+    k = _linear(h, P[prefix + "k_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
+    v = _q(_linear(h, P[prefix + "v_proj.weight"])).view(B, S, nh, hd).transpose(1, 2)
+    q = _q(q * cos + rotate_half(q) * sin)
+    k = _q(k * cos + rotate_half(k) * sin)
     att = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + add_mask
     att = torch.softmax(att, dim=-1, dtype=torch.float32)
-    o = (att @ v).transpose(1, 2).reshape(B, S, d)
-    return F.linear(o, P[prefix + "o_proj.weight"])
+    o = (_q(att) @ v).transpose(1, 2).reshape(B, S, d)
+    return _linear(o, P[prefix + "o_proj.weight"])
 
 
 def llama_forward(P: dict, cfg: OracleConfig, x: torch.Tensor, attention_mask=None) -> torch.Tensor:
@@ -249,10 +285,10 @@ def llama_forward(P: dict, cfg: OracleConfig, x: torch.Tensor, attention_mask=No
         add_mask = add_mask.masked_fill(pad, neg)
     for i in range(cfg.num_hidden_layers):
         p = f"model.layers.{i}."
-        x = x + llama_attention(P, cfg, p + "self_attn.", rms_norm(x, P[p + "input_layernorm.weight"], cfg.rms_norm_eps), cos, sin, add_mask)
+        x = _qs(x + llama_attention(P, cfg, p + "self_attn.", rms_norm(x, P[p + "input_layernorm.weight"], cfg.rms_norm_eps), cos, sin, add_mask))
         h = rms_norm(x, P[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-        h = F.silu(F.linear(h, P[p + "mlp.gate_proj.weight"])) * F.linear(h, P[p + "mlp.up_proj.weight"])
-        x = x + F.linear(h, P[p + "mlp.down_proj.weight"])
+        h = F.silu(_linear(h, P[p + "mlp.gate_proj.weight"])) * _linear(h, P[p + "mlp.up_proj.weight"])
+        x = _qs(x + _linear(h, P[p + "mlp.down_proj.weight"]))
     return rms_norm(x, P["model.norm.weight"], cfg.rms_norm_eps)
 
 
@@ -266,11 +302,11 @@ def forward(P: dict, cfg: OracleConfig, input_ids, attention_mask=None, labels=N
     """MMGPTLlamaForCausalLM.forward (llama_mmgpt.py:53-112).  Returns (loss|None, logits)."""
     if images is not None and input_ids.shape[1] != 1:
         feats = encode_images(P, cfg, images)
-        x = splice_image_features(P, cfg, input_ids, feats)
+        x = _qs(splice_image_features(P, cfg, input_ids, feats))
     else:
         x = F.embedding(input_ids, P["model.embed_tokens.weight"])
     h = llama_forward(P, cfg, x, attention_mask)
-    logits = F.linear(h, P["lm_head.weight"])
+    logits = _linear(h, P["lm_head.weight"])
     loss = shifted_ce(logits, labels) if labels is not None else None
     return loss, logits
 

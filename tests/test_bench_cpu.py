@@ -69,3 +69,40 @@ def test_bench_single_process_dry_run_and_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode != 0 and "nproc-per-node" in (p.stderr + p.stdout)
+
+
+def test_committed_pmc_traffic_summary_was_taken_on_the_committed_gemm_sources():
+    """the driver's bench line carried `roofline.traffic: null` because a GEMM source changed after the PMC passes.  The
+    newest profiles/rNN_gemm_traffic.json must carry the hash of the GEMM kernel sources as committed: the PMC pass
+    (tools/pmc_step_traffic.sh) is the LAST GPU action after any change to gemm*.hip / gemm_common.h / mh_common.h."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    path = bench.traffic_summary_path()
+    assert path is not None, "no profiles/rNN_gemm_traffic.json"
+    with open(path) as f:
+        t = json.load(f)
+    assert t["kernel_source_stamp"] == bench.kernel_source_stamp(), (os.path.basename(path), t["kernel_source_stamp"], bench.kernel_source_stamp())
+    assert t["traffic_over_algorithmic"] > 1.0 and t["traffic_bytes_per_launch"] > 0
+
+
+def test_skinny_split_k_is_a_bf16_launch_plan_and_never_allocates_during_capture(monkeypatch):
+    """ops._skinny_splitk_ok: split-K of the skinny projections applies to bf16 (the performance dtype); fp16 - the dtype BASELINE's logits
+    tolerance is stated in - keeps the one-pass summation order its full-depth bounds were measured with; a stream capture turns it off
+    (the workspace must not be allocated from a graph's private pool)."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from merlin_amd import ops as O
+
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(O, "SKINNY_SPLITK", True)
+    monkeypatch.setattr(O, "SKINNY_SPLITK_ALL", False)
+    assert O._skinny_splitk_ok(torch.bfloat16) and not O._skinny_splitk_ok(torch.float16)
+    monkeypatch.setattr(O, "SKINNY_SPLITK_ALL", True)
+    assert O._skinny_splitk_ok(torch.float16)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    assert not O._skinny_splitk_ok(torch.bfloat16)
+    monkeypatch.setattr(O, "SKINNY_SPLITK", False)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    assert not O._skinny_splitk_ok(torch.bfloat16)

@@ -145,11 +145,17 @@ def _accum_worker(rank, world, port, q):
             ok = False
         except RuntimeError as e:
             ok &= "no_sync" in str(e)
-        # ADVICE r2: after an optimizer step + zero_grad(set_to_none=False) the gradients are zero but still ATTACHED (the arena
-        # reports fresh = False); that is a valid new window, recognised by the weights having changed since the reduce ...
+        # an optimizer step WITHOUT zero_grad (or any in-place parameter edit) bumps the weight version while the arena still
+        # holds the all-reduced sums: accumulating onto them must still raise (it used to be let through: world * G_old + sum g_new)
         eng.weight_version += 1
-        for n in names:
-            A.gview(n).zero_()
+        try:
+            eng.backward(1.0)
+            ok = False
+        except RuntimeError as e:
+            ok &= "no_sync" in str(e)
+        # ADVICE r2: after an optimizer step + zero_grad(set_to_none=False) the gradients are zero but still ATTACHED (the arena
+        # reports fresh = False); that is a valid new window, recognised by the arena holding zeros ...
+        A.gflat.zero_()
         eng.backward(float(rank + 1))
         ok &= all(bool((A.gview(n) == float(sum(r + 1 for r in range(world)))).all()) for n in names)
         # ... and without a step (skipped update) through GradSync.zero_grad()

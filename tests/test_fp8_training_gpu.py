@@ -358,3 +358,52 @@ def test_fp8_training_on_cfg5_interleave_layout_vs_oracle():
         cos = float(a @ b / (a.norm() * b.norm()))
         print("   ", k, round(cos, 4), round(float(a.norm() / b.norm()), 4))
         assert cos > 0.97 and abs(float(a.norm() / b.norm()) - 1) < 0.10, (k, cos)
+
+
+def test_fp8_training_step_at_cfg5_real_length_S8192_vs_oracle():
+    """BASELINE cfg 5 at its REAL sequence length: one MMC4-style interleave document of S = 8192 with 4 images through the
+    real-width 2+2-layer model with the fp8 training step on (decoder, CLIP tower and lm_head Linears on the scaled-fp8 MFMA).  Forward
+    (logits, loss) against the fp32 CPU oracle - forward only on the host: the oracle's saved [32, S, S] probabilities of a backward would
+    not fit - and the HIP backward at that length is run, finite, deterministic and moves the loss down under one AdamW step."""
+    import psutil
+
+    from merlin_amd import synth
+    from merlin_amd.optim import FusedAdamW
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+    from test_model_gpu import _build
+
+    assert psutil.virtual_memory().available >= 80e9, "the fp32 CPU oracle materialises [32, S, S] attention scores: ~60 GB of host memory at S = 8192"
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    cfg = C.medium_cfg()
+    model = _build(cfg, torch.bfloat16)
+    model.fp8_training = True
+    model.engine.fp8_tower = True
+    batch = synth.interleave_batch(B=1, S=8192, n_images=4)
+    assert batch["input_ids"].shape == (1, 8192) and batch["images"][0].shape[0] == 4
+    db = dict(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
+              images=[im.cuda() for im in batch["images"]])
+    out = model(**db)
+    assert model.engine.last_fp8 == dict(decoder=True, tower=True, head=True), model.engine.last_fp8
+    out.loss.backward()
+    g1 = model.engine.arena.gflat.clone()
+    assert bool(torch.isfinite(g1.float()).all())
+    with torch.no_grad():
+        P = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+        loss_ref, logits_ref = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    d = (out.logits.float().cpu() - logits_ref)
+    rng = float(logits_ref.abs().max())
+    mx, rms = float(d.abs().max()) / rng, float(d.pow(2).mean().sqrt()) / rng
+    print(f"[fp8 train cfg 5 S=8192] logits max {mx:.3e} rms {rms:.3e} loss {float(out.loss):.5f} oracle {float(loss_ref):.5f}")
+    # the fp8 step's stated tolerances (e4m3 operands, DESIGN §7): as at S = 2432
+    assert mx < 0.20 and rms < 0.04, (mx, rms)
+    assert abs(float(out.loss) - float(loss_ref)) < 2e-2 * float(loss_ref)
+    del P, logits_ref, d
+    for p in model.parameters():
+        p.grad = None
+    model(**db).loss.backward()
+    assert torch.equal(model.engine.arena.gflat, g1), "the fp8 step is deterministic at S = 8192"
+    FusedAdamW(model.engine, lr=1e-3).step()
+    with torch.no_grad():
+        l2 = model(**db).loss
+    assert float(l2) < float(out.loss), "one AdamW step on this batch must lower its loss"

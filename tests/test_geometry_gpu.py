@@ -169,8 +169,8 @@ def test_packed_sequence_at_benchmark_length_vs_oracle(layout):
     from merlin_amd import synth
     from oracle import ref_cpu as R
 
-    if psutil.virtual_memory().available < 80e9:
-        pytest.skip("the fp32 CPU oracle materialises [32, S, S] attention scores: needs ~60 GB of free host memory at S = 8192")
+    # (a hard failure, not a skip: a box too small for the oracle must not silently drop this evidence - VERDICT r3)
+    assert psutil.virtual_memory().available >= 80e9, "the fp32 CPU oracle materialises [32, S, S] attention scores: needs ~60 GB of free host memory at S = 8192"
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     dtype = torch.float16
     cfg, model = _real_width_2layer(dtype)
@@ -221,8 +221,8 @@ def test_full_depth_7b_backward_vs_oracle(dtype):
     from oracle import ref_cpu as R
     from test_model_gpu import _build
 
-    if psutil.virtual_memory().available < 80e9:
-        pytest.skip("needs ~70 GB of free host memory for the fp32 CPU oracle of the 7B model")
+    # (a hard failure, not a skip: a box too small for the oracle must not silently drop this evidence - VERDICT r3)
+    assert psutil.virtual_memory().available >= 80e9, "needs ~70 GB of free host memory for the fp32 CPU oracle of the 7B model"
     cfg, batch = C.get_case("full_cfg1")
     model = _build(cfg, dtype)
     out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),

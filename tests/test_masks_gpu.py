@@ -175,3 +175,57 @@ def test_left_padded_batched_generate_matches_unpadded_prompts():
         m.generate(ids.cuda(), images=images, attention_mask=am.cuda(), definitely_not_an_option=1)
     with pytest.raises(NotImplementedError):
         m.generate(ids.cuda(), images=images, attention_mask=am.cuda(), return_dict_in_generate=True)
+
+
+def test_mask_classification_does_not_depend_on_strict_checks_and_generate_follows_the_engine():
+    """with engine.strict_checks = False a left-padded batch used to be treated as dense (pads became valid keys) while
+    generate() classified the mask on its own.  The classification is now always made on the device, and generate() follows the
+    engine's decision (cache.rpos): strict on / off give bit-identical logits on a left-padded batch, and a right-padded batch sent
+    through engine.force_unpad generates the same tokens as through the lens fast path."""
+    from oracle import cases as C
+    from test_generation_gpu import GOLD, _model
+    from test_model_gpu import _build, _to_dev
+
+    cfg, batch = C.get_case("tiny_padbatch")
+    b = _to_dev(batch)
+    model = _build(cfg, torch.float16)
+    am = b["attention_mask"].bool()
+    lens = am.sum(1)
+    S = am.shape[1]
+    # left-pad: move every row's valid tokens to the end
+    ids_l, lab_l, am_l = torch.zeros_like(b["input_ids"]), torch.full_like(b["labels"], -100), torch.zeros_like(am)
+    for i in range(am.shape[0]):
+        n = int(lens[i])
+        ids_l[i, S - n:], lab_l[i, S - n:], am_l[i, S - n:] = b["input_ids"][i, :n], b["labels"][i, :n], True
+    res = []
+    with torch.no_grad():
+        for strict in (True, False):
+            model.engine.strict_checks = strict
+            out = model(input_ids=ids_l, attention_mask=am_l, labels=lab_l, images=b["images"])
+            res.append((out.logits[am_l].clone(), out.loss.clone()))
+    model.engine.strict_checks = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    if int(lens.min()) < S:  # the batch really has padding: a dense reading would differ
+        with torch.no_grad():
+            dense = model(input_ids=ids_l, attention_mask=None, labels=lab_l, images=b["images"]).logits[am_l]
+        assert not torch.equal(dense, res[0][0])
+    # generate(): right-padded prompts through the fast path and through force_unpad
+    rec = GOLD["cases"][0]
+    cfg2, batch2, m = _model("tiny_padbatch", rec["logit_gain"])
+    kw = dict(max_new_tokens=6, do_sample=False, eos_token_id=rec["eos_token_id"], pad_token_id=0)
+    ids2, am2 = batch2["input_ids"].cuda(), batch2["attention_mask"].cuda()
+    images2 = [im.cuda() for im in batch2["images"]]
+    fast = m.generate(ids2, images=images2, attention_mask=am2, **kw).cpu()
+    m.engine.force_unpad = True
+    try:
+        general = m.generate(ids2, images=images2, attention_mask=am2, **kw).cpu()
+    finally:
+        m.engine.force_unpad = False
+    # fast path: continuation compacted behind each row's own length; general path (HF layout): appended after the padded prompt
+    P = ids2.shape[1]
+    l2 = am2.sum(1).cpu()
+    agree = 0
+    for i in range(ids2.shape[0]):
+        n = min(fast.shape[1] - int(l2[i]), general.shape[1] - P)
+        agree += int((fast[i, int(l2[i]):int(l2[i]) + n] == general[i, P:P + n]).sum())
+    assert agree >= 0.8 * 6 * ids2.shape[0], (fast, general)  # (RoPE position offsets differ between the two layouts: fp16 ties aside)

@@ -118,12 +118,12 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     """BASELINE cfg 1/2 at FULL size (24-layer ViT-L/14-336 + 32-layer Llama-7B, S=613): logits slice,
     per-position logsumexp and loss of the HIP path vs the REAL reference's fp32 CPU outputs
     (tests/golden/full_cfg1.npz, generated by oracle/make_golden.py full).  Tolerance at full depth (32 layers
-    of 16-bit residual stream): logits max 6e-3 / rms 1.25e-3 (fp16), 5e-2 / 1e-2 (bf16) of max|logit|, loss 2e-3 / 1e-2."""
+    of 16-bit residual stream): logits max 5e-3 / rms 1.25e-3 (fp16), 5e-2 / 1e-2 (bf16) of max|logit|, loss 2e-3 / 1e-2; with the fp32
+    residual stream (the engine's default) 2.6e-3 / 6e-4 and 2.2e-2 / 4.8e-3."""
     from oracle import cases as C
 
     path = os.path.join(GOLD, "full_cfg1.npz")
-    if not os.path.exists(path):
-        pytest.skip("full golden not generated")
+    assert os.path.exists(path), "tests/golden/full_cfg1.npz is a committed fixture (oracle/make_golden.py full)"
     g = np.load(path)
     cfg, batch = C.get_case("full_cfg1")
     assert np.array_equal(g["input_ids"], batch["input_ids"].numpy())
@@ -138,10 +138,13 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     # Two statistics.  The rms error over the slice is stable to the last digit under any change of summation order (measured, one-pass
     # GEMMs / split-K for the skinny projections: fp16 1.066e-3 / 1.072e-3, fp16 + fp32 stream 5.210e-4 / 5.203e-4, bf16 8.50e-3 / 8.49e-3,
     # bf16 + fp32 stream 4.16e-3 / 4.10e-3) and is held within 15 %.  The maximum is ONE element of 40 k and scatters by +-25 % with
-    # rounding order (same pairs: 4.59e-3 / 5.08e-3, 2.11e-3 / 2.65e-3, 3.49e-2 / 3.26e-2, 1.76e-2 / 1.93e-2): its bound has that margin.
-    tl, trms, tloss = (6e-3, 1.25e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1.0e-2, 1e-2)
+    # rounding order (same pairs: 4.59e-3 / 5.08e-3, 2.11e-3 / 2.65e-3, 3.49e-2 / 3.26e-2, 1.76e-2 / 1.93e-2).  Its bounds are the ones the
+    # one-pass summation order was first measured under (5e-3 / 2.6e-3 fp16, 5e-2 / 2.2e-2 bf16): fp16 - the dtype BASELINE's tolerance is
+    # stated in - keeps that order (ops._skinny_splitk_ok: split-K of the skinny projections is a bf16-only launch plan), bf16 meets
+    # them with split-K.  tests/test_parity_floor_gpu.py holds the same errors against the measured 16-bit-operand floor.
+    tl, trms, tloss = (5e-3, 1.25e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1.0e-2, 1e-2)
     if stream == "fp32":
-        tl, trms = (3.2e-3, 6.0e-4) if dtype == torch.float16 else (2.4e-2, 4.8e-3)
+        tl, trms = (2.6e-3, 6.0e-4) if dtype == torch.float16 else (2.2e-2, 4.8e-3)
     dlt = got - g["logits_slice"]
     err = np.abs(dlt).max() / float(g["logits_absmax"])
     rms = float(np.sqrt((dlt.astype(np.float64) ** 2).mean())) / float(g["logits_absmax"])
@@ -202,10 +205,12 @@ def test_medium_backward_grad_norms_vs_reference_golden(dtype):
     fp16: every sampled cosine >= 0.999 and norms within 1 % - the strict check of the backward maths.
     bf16 (8x coarser mantissa): cosine >= 0.99, norms within 5 %; the 512-element strided sample of lm_head's gradient is
     the exception: it consists of non-label vocabulary rows whose entries are sums of ~33 softmax probabilities
-    p ~ 3e-5, and bf16 logit noise (|d logit| ~ 0.1) moves each p by ~10 %, so that sample's cosine is noise
+    p ~ 3e-5, and bf16 logit noise (|d logit| ~ 0.1) moves each p by ~10 %, so that 512-element sample's cosine is noise
     (measured anywhere from 0.01 to 0.96 depending on rounding details upstream; 0.9999 in fp16) - its norm is pinned tightly and the
-    WHOLE tensor is held to the fp16 run's (cosine > 0.97)."""
+    WHOLE tensor is held against the CPU ORACLE's lm_head gradient (fp32 autograd of oracle/ref_cpu.py on the same weights and batch:
+    an oracle check in both dtypes, not a comparison of two HIP runs)."""
     from oracle import cases as C
+    from oracle import ref_cpu as R
 
     cfg, batch = C.get_case("medium_cfg1")
     g = np.load(os.path.join(GOLD, "medium_cfg1.npz"))
@@ -229,20 +234,23 @@ def test_medium_backward_grad_norms_vs_reference_golden(dtype):
         if strict:
             cmin, rtol = 0.999, 0.01
         else:
-            cmin, rtol = (-1.0 if k == "lm_head.weight" else 0.99), 0.05  # (lm_head's bf16 sample is noise: whole tensor below)
+            cmin, rtol = (-1.0 if k == "lm_head.weight" else 0.99), 0.05  # (lm_head's bf16 SAMPLE is noise: whole tensor vs the oracle below)
         if cos < cmin or abs(ratio - 1) > rtol:
             bad.append((k, cos, ratio))
     assert n > 30
     assert not bad, bad[:8]
-    if not strict:  # lm_head.weight's bf16 gradient, whole tensor, against the fp16 run's (which meets the strict check above)
-        gb = dict(model.named_parameters())["lm_head.weight"].grad.float().clone()
-        del model, out
-        torch.cuda.empty_cache()
-        m16 = _build(cfg, torch.float16)
-        m16(**_to_dev(batch)).loss.backward()
-        g16 = dict(m16.named_parameters())["lm_head.weight"].grad.float()
-        cos = float((gb * g16).sum() / (gb.norm() * g16.norm()))
-        assert cos > 0.97 and abs(float(gb.norm() / g16.norm()) - 1) < 0.05, cos
+    # lm_head.weight's gradient, whole tensor, against the oracle's (only that leaf requires grad: autograd stops at the head)
+    gh = dict(model.named_parameters())["lm_head.weight"].grad.float().cpu()
+    P = R.make_params(cfg, seed=0)
+    P["lm_head.weight"].requires_grad_(True)
+    loss_ref, _ = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    gr = P["lm_head.weight"].grad
+    assert abs(float(gr.double().norm()) / float(g["grad/lm_head.weight/norm"]) - 1) < 1e-4  # the oracle's gradient IS the reference's
+    cos = float((gh.double() * gr.double()).sum() / (gh.double().norm() * gr.double().norm()))
+    ratio = float(gh.double().norm() / gr.double().norm())
+    print(f"[medium lm_head.weight grad {dtype}] whole-tensor cosine vs oracle {cos:.5f} norm ratio {ratio:.4f}")
+    assert cos > (0.9995 if strict else 0.97) and abs(ratio - 1) < (0.01 if strict else 0.05), (cos, ratio)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -1059,8 +1059,11 @@ def test_skinny_gemm_split_k_with_epilogues(ops, dtype, M, N, K, monkeypatch):
         return r
 
     monkeypatch.setattr(O, "SKINNY_SPLITK", True)
+    monkeypatch.setattr(O, "SKINNY_SPLITK_ALL", True)  # (the default keeps fp16 on the one-pass order: ops._skinny_splitk_ok)
     split = run()
     again = run()
+    # one grow-only workspace per (device, stream): repeated and differently sized calls on this stream share ONE buffer
+    assert sum(1 for k in O._splitk_ws if k[1] == torch.cuda.current_stream().cuda_stream) == 1
     monkeypatch.setattr(O, "SKINNY_SPLITK", False)
     one = run()
     want = dict(nt=ref, nn=ref, bias=z, gelu=z * torch.sigmoid(1.702 * z), resid=ref + resid.float(), bias_resid=z + resid.float(), f32=ref,

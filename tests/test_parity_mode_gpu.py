@@ -63,8 +63,8 @@ def test_parity_mode_at_benchmark_sequence_lengths(layout):
     from oracle import ref_cpu as R
     from test_model_gpu import _build
 
-    if psutil.virtual_memory().available < 80e9:
-        pytest.skip("fp32 CPU oracle at S = 8192 needs ~60 GB of free host memory")
+    # (a hard failure, not a skip: a box too small for the oracle must not silently drop this evidence - VERDICT r3)
+    assert psutil.virtual_memory().available >= 80e9, "fp32 CPU oracle at S = 8192 needs ~60 GB of free host memory"
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     cfg = C.medium_cfg()
     model = _build(cfg, torch.bfloat16)

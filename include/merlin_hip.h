@@ -141,6 +141,20 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
                    void* stream);
 
+/* Several weight gradients over the SAME token count in one launch: out_p[M_p, N_p] (+)= dy_p[T, M_p]^T x_p[T, N_p] for p < n <= 8, both
+ * operands as they lie in memory (K-strided), any T (rows >= T read as zeros), 16-bit outputs.  One block per 256 x 256 output tile of
+ * any of the problems: the four Linears of a CLIP encoder layer (48 + 16 + 64 + 64 tiles; autograd of HF CLIPEncoderLayer,
+ * clip_encoder.py:74-82) fill the chip together for the whole contraction where each of them alone needs split-K with fp32 partials.
+ * Returns MH_ERR_SHAPE when a problem does not meet the 4-wave kernel's conditions (M, N, ld % 8, 16-byte aligned bases, operand
+ * spans < 4 GiB): nothing is launched then and the caller issues mh_gemm_splitk per problem. */
+typedef struct MhWgradProblem {
+  const void* dy; int64_t lddy;   /* [T, M] */
+  const void* x;  int64_t ldx;    /* [T, N] */
+  void* out;      int64_t ldo;    /* [M, N], 16-bit */
+  int M, N, accumulate, reserved;
+} MhWgradProblem;
+int mh_wgrad_grouped(const MhWgradProblem* problems, int n, int T, int dt, void* stream);
+
 /* Split-K with mh_gemm's full epilogue (bias, quick-GELU, residual, accumulate, fp32 store - applied by the fixed-order reduce pass
  * exactly as the one-pass store phase applies them): for products with few output tiles and a long contraction, e.g. the o / down
  * projections and the dgrads of a 613-token sequence (48 tiles for 256 CUs).  ws: splits * M * N floats; N % 4 == 0, ldc % 4 == 0;

@@ -208,15 +208,26 @@ struct RopeSpec {
   const float* tab = nullptr; int S = 0, D = 0, cols = 0;
   int sw_mode = 0, sw_ff = 0; void* sw_out = nullptr; const void* sw_in = nullptr; int64_t sw_ldo = 0, sw_ldi = 0;  // fused SwiGLU
 };
-// Shapes that go to gemm_w4 by default (see the call site).  g_w4_mask: bit 0 = TN (wgrad), bit 1 = NN (dgrad), bit 2 = NT (measured: 3 is best in the step).
-int g_w4_mask = 3 | 8;  // (bit 3: the fp8 NT products of the fp8 training step)
+// Shapes that go to gemm_w4 by default (see the call site).  g_w4_mask: bit 0 = TN (wgrad, incl. its split-K form), bit 1 = NN (dgrad),
+// bit 2 = plain / residual NT, bit 3 = the fp8 NT products of the fp8 training step, bit 4 = the fused forward forms (q|k|v + RoPE,
+// gate|up + SwiGLU: rotated / gated on the fp32 accumulators), bit 5 = the SwiGLU-backward dgrad, bit 6 = fp32 outputs of NT products
+// (lm_head logits, the fp32 residual streams' accumulating projections), bit 7 = the fused forward forms at any size (see the call site).
+// Measured per bit in the step: profiles/r04_gemm_w4_policy.txt.
+int g_w4_mask = 3 | 8 | 16 | 32 | 64;
 extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
-static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi) {
-  const int form = (a_ks && b_ks) ? 1 : (b_ks ? 2 : (a_ks ? 0 : 4));
-  if (!(g_w4_mask & form)) return false;
+static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi, const RopeSpec& fx) {
   (void)M; (void)N;
-  if (form == 4) return K >= 4096 && ((epi & ~MH_EPI_ACCUM) == 0 || (epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL);
-  return K >= 4096 && (epi & ~MH_EPI_ACCUM) == 0;
+  if (K < 4096) return false;
+  if (fx.sw_mode == 1 || fx.tab) return (g_w4_mask & 16) != 0;
+  if (fx.sw_mode == 2) return (g_w4_mask & 32) != 0;
+  const int form = (a_ks && b_ks) ? 1 : (b_ks ? 2 : (a_ks ? 0 : 4));
+  if (epi & MH_EPI_OUT_F32) {
+    if (form == 1) return (g_w4_mask & 1) != 0;   // split-K partials of a weight gradient
+    return form == 4 && (g_w4_mask & 64) != 0;
+  }
+  if (!(g_w4_mask & form)) return false;
+  if (form == 4) return (epi & ~MH_EPI_ACCUM) == 0 || (epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL;
+  return (epi & ~MH_EPI_ACCUM) == 0;
 }
 
 static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
@@ -382,6 +393,26 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
 }
 
+extern "C" int mh_wgrad_grouped(const MhWgradProblem* pr, int n, int T, int dt, void* stream) {
+  if (!pr || n < 1 || n > 8 || T <= 0) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  GemmArgs gs[8];
+  for (int i = 0; i < n; ++i) {
+    const MhWgradProblem& q = pr[i];
+    if (!q.dy || !q.x || !q.out || q.M <= 0 || q.N <= 0) return MH_ERR_ARG;
+    if ((q.lddy & 7) || (q.ldx & 7) || !aligned16(q.dy) || !aligned16(q.x)) return MH_ERR_SHAPE;
+    GemmArgs g{};
+    g.A = (const uint16_t*)q.dy; g.B = (const uint16_t*)q.x; g.C = q.out;
+    g.lda = q.lddy; g.ldb = q.ldx; g.ldc = q.ldo;
+    g.M = q.M; g.N = q.N; g.K = T; g.epi = q.accumulate ? MH_EPI_ACCUM : 0;
+    g.splits = 1; g.gm = g_gemm_gm; g.vec_ok = 1;
+    g.tiles_m = (q.M + 255) / 256; g.tiles_n = (q.N + 255) / 256;
+    if (!w4_can_run(g, 1, 1)) return MH_ERR_SHAPE;
+    gs[i] = g;
+  }
+  return launch_gemm_w4_grouped(gs, n, dt, g_gemm_gm, as_stream(stream));
+}
+
 extern "C" int mh_gemm_splitk_max(int M, int N, int K) {
   const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
   const int nk = (K + BK - 1) / BK;
@@ -521,9 +552,13 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   // everything it can run there, (256) nothing.
   {
     g.tiles_m = (M + 255) / 256;
-    g.tiles_n = (N + 255) / 256;
-    const bool can = g_force_kernel != 256 && g_force_kernel != 128 && w4_can_run(g, a_kstrided, b_kstrided);
-    const bool want = g_force_kernel == 4 || (g_force_kernel == 0 && big && w4_policy(a_kstrided, b_kstrided, M, N, K, epilogue));
+    g.tiles_n = rope.sw_mode == 1 ? (rope.sw_ff + 127) / 128 : (N + 255) / 256;  // (SwiGLU forward: a tile = 2 x (64 gate + 64 up) columns)
+    const bool can = g_force_kernel != 256 && g_force_kernel != 128 && w4_can_run(g, a_kstrided, b_kstrided) && w4_has_kernel(g, a_kstrided, b_kstrided);
+    // bit 7 of the policy mask: the fused forward forms go to the 4-wave kernel at ANY size (a 613-token sequence has 144 tiles) - they
+    // rotate / gate the fp32 accumulators there, one rounding less than the 8-wave kernel's staged forms (parity; measured: DESIGN §4)
+    const bool fused_any = (g_w4_mask & 128) && (rope.tab || rope.sw_mode == 1);
+    const bool fills = big || fused_any || (int64_t)g.tiles_m * g.tiles_n * splits >= 192;
+    const bool want = g_force_kernel == 4 || (g_force_kernel == 0 && fills && w4_policy(a_kstrided, b_kstrided, M, N, K, epilogue, rope));
     if (can && want) return launch_gemm_w4(g, dt, a_kstrided, b_kstrided, as_stream(stream));
   }
   if (rope.sw_mode == 1) {  // a tile = 128 gate + 128 up columns

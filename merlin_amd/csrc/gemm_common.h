@@ -232,9 +232,12 @@ int launch_gemm_nt_256(const GemmArgs& g, int dt, hipStream_t stream);
 // operand layouts: K-contiguous (0) or K-strided (1), see gemm256.hip
 int launch_gemm_256(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
 int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0);      // tools/dev_arms/gemm256w4.hip (first 4-wave arm)
-// gemm_w4.hip: 4 waves x 128x128 per wave, all operand layouts, staged 16-bit epilogue (plain / bias / gelu / residual / accumulate)
+// gemm_w4.hip: 4 waves x 128x128 per wave, all operand layouts; staged 16-bit epilogue (plain / residual / accumulate), fp32 stores, and the
+// fused RoPE / SwiGLU / SwiGLU-backward forms on the fp32 accumulators; split-K (fp32 partials); K tails of K-strided operands
 bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided);
+bool w4_has_kernel(const GemmArgs& g, int a_kstrided, int b_kstrided);  // the (epilogue kind, layout) pair is instantiated
 int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
+int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStream_t stream);  // n weight gradients (TN) over one K, one launch
 bool w4_f8_can_run(const GemmArgs& g);  // fp8 operands (no block exponents), see gemm_w4.hip
 int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream);
 int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA

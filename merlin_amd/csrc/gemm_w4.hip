@@ -89,16 +89,37 @@ struct Sched {
   }
 };
 
-template <int DT, bool AKS, bool BKS>
-__global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// Epilogue kinds (one kernel instantiation each: a run-time switch between 64-tile store blocks makes hipcc spill the accumulators
+// around the merge).  The fused forms work on the fp32 ACCUMULATORS - a lane holds a rotary pair (c, c + 64) resp. a (gate, up)
+// pair of one token in two accumulator tiles of its own - and round once, where the 8-wave kernel's staged forms rotate / gate the
+// already rounded 16-bit tile (bit-identical to the unfused kernels; one rounding more).
+enum { EK_STD = 0,         // 16-bit C through the staged store: plain / residual, optionally accumulating
+       EK_F32 = 1,         // fp32 C (lm_head logits; split-K partials at C + split * c_split)
+       EK_F32ACC = 2,      // fp32 C += (the fp32 residual streams: x += o Wo^T, x += act Wd^T)
+       EK_ROPE = 3,        // q|k|v projection, RoPE of the q / k heads (D = 128: a wave's 128 columns are one head)
+       EK_SWIGLU = 4,      // gate|up projection: a tile = 2 x (64 gate + 64 up) columns; C = gu, sw_out = act = silu(gate) * up
+       EK_SWIGLU_BWD = 5 };  // dact = dY Wd -> sw_out = dgu from sw_in = gu (dact never stored)
+
+// max(0, span - off) in scalar arithmetic.  (Written as `off < span ? span - off : 0` or `span - min(off, span)` hipcc recognises an
+// unsigned saturating subtract, which exists only as a VALU instruction (v_sub_u32 clamp): the descriptor word would have to come back
+// through a VGPR -> SGPR copy the backend refuses.)
+__device__ __forceinline__ unsigned left_after(unsigned span, unsigned off) {
+  const long long d = (long long)span - (long long)off;
+  return d > 0 ? (unsigned)d : 0u;
+}
+
+template <int DT, bool AKS, bool BKS, int EK>
+__device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, int tn, int ky) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int tm, tn;
-  tile_of_block(g, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = g.K / BK;
+  const int m0 = tm * 256, n0 = tn * (EK == EK_SWIGLU ? 128 : 256);
+  // K range of this block: all of K, or split `ky` of g.splits (an even number of K-tiles each; K-strided operands may end inside
+  // a tile - rows k >= K read as zeros through the buffer descriptor's range check, see copy_ld)
+  const int nkt = (g.K + 2 * BK - 1) / (2 * BK) * 2;
+  const int per = g.splits > 1 ? ((nkt / 2 + g.splits - 1) / g.splits) * 2 : nkt;
+  const int kt0 = ky * per;
+  const int nk = min(per, nkt - kt0);
   constexpr int NRA = AKS ? 16 : 8, NRB = BKS ? 16 : 8, NR = NRA + NRB;
   using SC = Sched<NR>;
 
@@ -118,21 +139,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
     }
     if constexpr (!BKS) {
       const int row = wave * 64 + j * 8 + (lane >> 3);
-      voffB[j] = (int)((int64_t)min(n0 + row, g.N - 1) * g.ldb * 2 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
+      int src = n0 + row;
+      if constexpr (EK == EK_SWIGLU) {  // part rows [64 q, 64 q + 64): q = 2 * (column half) + (0 gate | 1 up)
+        const int q = row >> 6;
+        src = (q & 1) * g.sw_ff + n0 + (q >> 1) * 64 + (row & 63);
+      }
+      voffB[j] = (int)((int64_t)min(src, g.N - 1) * g.ldb * 2 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
     } else {
       const int qd = (j & 3) * 256 + wave * 64 + lane, k = qd >> 4, cc = qd & 15;
       const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
       voffB[j] = (int)(((int64_t)k * g.ldb + min(n0 + (j >> 2) * 128 + col, g.N - 8)) * 2);
     }
   }
-  const int kstepA = AKS ? (int)((int64_t)BK * g.lda * 2) : BK * 2;  // source bytes per K-tile (host guarantees K * ld * 2 < 2^32)
-  const int kstepB = BKS ? (int)((int64_t)BK * g.ldb * 2) : BK * 2;
-  auto make_rs = [](const void* p_) {
-    const uint64_t a_ = (uint64_t)(uintptr_t)p_;
+  const unsigned kstepA = AKS ? (unsigned)((int64_t)BK * g.lda * 2) : BK * 2;  // source bytes per K-tile (host guarantees K * ld * 2 < 2^32)
+  const unsigned kstepB = BKS ? (unsigned)((int64_t)BK * g.ldb * 2) : BK * 2;
+  // operand bases at this block's first K-tile (wave-uniform) and, for K-strided operands, the bytes from there to the end of row K - 1
+  const uint64_t baseA = (uint64_t)(uintptr_t)g.A + (uint64_t)kt0 * kstepA, baseB = (uint64_t)(uintptr_t)g.B + (uint64_t)kt0 * kstepB;
+  const unsigned spanA = AKS ? (unsigned)((int64_t)(g.K - kt0 * BK) * g.lda * 2) : 0u;
+  const unsigned spanB = BKS ? (unsigned)((int64_t)(g.K - kt0 * BK) * g.ldb * 2) : 0u;
+  auto make_rs = [](uint64_t a_, unsigned nrec) {
     return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)a_),
-                 __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_ >> 32) & 0xffffu)), -1, 0x00020000};
+                 __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_ >> 32) & 0xffffu)), __builtin_amdgcn_readfirstlane((int)nrec), 0x00020000};
   };
-  const i32x4 rsA = make_rs(g.A), rsB = make_rs(g.B);
+  const i32x4 rsA = make_rs(baseA, 0xffffffffu), rsB = make_rs(baseB, 0xffffffffu);
   const unsigned lds0 = lds_addr_of(smem);
   // the wave's share of a part starts at wave * 8 KiB (K-contiguous: 64 rows) or wave * 1 KiB inside each 4-KiB group (K-strided)
   const unsigned w_kc = lds0 + (unsigned)wave * 8192u, w_ks = lds0 + (unsigned)wave * 1024u;  // (wave-uniform: SGPRs)
@@ -144,17 +173,51 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
     const unsigned base_ = ks ? w_ks : w_kc;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
     asm volatile("s_add_u32 m0, %0, %1" ::"s"(base_), "n"(imm) : "scc");
   };
-  auto copy_ld = [&](auto C_, int t) {
+  // K-contiguous operand: fixed descriptor, the K advance is the scalar offset.  K-strided operand: the K advance goes into the
+  // descriptor's BASE and its range shrinks to the bytes left up to row K - 1 (a handful of scalar instructions per K-tile), so that
+  // rows k >= K of the last tile(s) fail the hardware range check and arrive in LDS as zeros: K need not be a multiple of the K-tile
+  // (the CLIP tower's 27 696 tokens) - the scalar offset of a buffer instruction takes no part in that check, the base does.
+  // The descriptors of tile t are built from scalar values only (kernel arguments, block ids, the loop counter) and are pinned in SGPRs
+  // by tile_rs() at the START of a phase, many instructions ahead of the copies that read them: the copies are inline asm, so the
+  // compiler's hazard recogniser cannot see that a VMEM instruction reads those SGPRs, and a descriptor word written by a VALU
+  // instruction (v_readfirstlane) just before it would be read stale.
+  struct TileRs { i32x4 a, b; unsigned sa, sb; };
+  auto tile_rs = [&](int t) {
+    TileRs r;
+    if constexpr (AKS) {
+      const unsigned off = (unsigned)t * kstepA;
+      const uint64_t ba = baseA + off;
+      r.a = i32x4{(int)(uint32_t)ba, (int)(uint32_t)((ba >> 32) & 0xffffu), (int)left_after(spanA, off), 0x00020000};
+      r.sa = 0;
+    } else {
+      r.a = rsA;
+      r.sa = (unsigned)t * (unsigned)(BK * 2);
+    }
+    if constexpr (BKS) {
+      const unsigned off = (unsigned)t * kstepB;
+      const uint64_t bb = baseB + off;
+      r.b = i32x4{(int)(uint32_t)bb, (int)(uint32_t)((bb >> 32) & 0xffffu), (int)left_after(spanB, off), 0x00020000};
+      r.sb = 0;
+    } else {
+      r.b = rsB;
+      r.sb = (unsigned)t * (unsigned)(BK * 2);
+    }
+    asm volatile("" : "+s"(r.a), "+s"(r.b), "+s"(r.sa), "+s"(r.sb));
+    return r;
+  };
+  auto copy_ld = [&](auto C_, const TileRs& r) {
     constexpr int c = decltype(C_)::value;
-    const int vo = c < 8 ? voffA[c & 7] : voffB[c & 7];
-    const i32x4 rs = c < 8 ? rsA : rsB;
-    const unsigned soff = (unsigned)t * (unsigned)(c < 8 ? kstepA : kstepB);
+    constexpr bool isA = c < 8;
+    const int vo = isA ? voffA[c & 7] : voffB[c & 7];
+    const i32x4 rs = isA ? r.a : r.b;
+    const unsigned soff = isA ? r.sa : r.sb;
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
   };
   auto issue_tile = [&](auto BUF_, int t) {  // prologue form (all 16 copies back to back)
+    const TileRs r = tile_rs(t);
     w4_for<16>([&](auto C_) {
       copy_m0(C_, BUF_);
-      copy_ld(C_, t);
+      copy_ld(C_, r);
     });
   };
 
@@ -234,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   // hipcc spills hundreds of registers around control flow that merges paths through these hand-placed asm streams)
   auto phase_e = [&](auto BUF_, int t) {  // MFMAs on set 0 (tile t, k 0..31); fetch set 1 of tile t
     constexpr bool loads = true;
-    const int tl = min(t + 2, nk - 1);
+    const TileRs tr = tile_rs(min(t + 2, nk - 1));
     w4_for<64>([&](auto SL_) {
       constexpr int sl = decltype(SL_)::value;
       mfma_slot(S0{}, SL_);
@@ -245,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
       }
       if constexpr (loads && SC::e_copy(sl)) {
         if constexpr ((sl - SC::E0) % SC::PE == 0) copy_m0(integral_constant<int, SC::e_copy_index(sl)>{}, BUF_);
-        else copy_ld(integral_constant<int, SC::e_copy_index(sl)>{}, tl);
+        else copy_ld(integral_constant<int, SC::e_copy_index(sl)>{}, tr);
       }
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -254,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   auto phase_o = [&](auto BUF_, int t) {  // MFMAs on set 1 (tile t, k 32..63); fetch set 0 of tile t+1
     constexpr int bu = decltype(BUF_)::value;
     constexpr bool loads = true;
-    const int tl = min(t + 2, nk - 1);
+    const TileRs tr = tile_rs(min(t + 2, nk - 1));
     using NB = integral_constant<int, 1 - bu>;
     w4_for<64>([&](auto SL_) {
       constexpr int sl = decltype(SL_)::value;
@@ -266,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
       constexpr bool cp = loads && SC::o_copy(sl);
       if constexpr (cp) {
         if constexpr ((sl - SC::O0) % SC::PO == 0) copy_m0(integral_constant<int, SC::o_copy_index(sl)>{}, BUF_);
-        else copy_ld(integral_constant<int, SC::o_copy_index(sl)>{}, tl);
+        else copy_ld(integral_constant<int, SC::o_copy_index(sl)>{}, tr);
       }
       constexpr int nread = SC::o_read_index(sl, loads);
       if constexpr (!cp && sl >= 4 && nread < NR) read1(NB{}, S0{}, integral_constant<int, nread>{});  // (past the last tile: dead data, unused)
@@ -285,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   W4_FENCE();
 
-  for (int t = 0; t < nk; t += 2) {  // nk is even (host): tile t from buffer 0, tile t+1 from buffer 1
+  for (int t = 0; t < nk; t += 2) {  // nk is even: tile t from buffer 0, tile t+1 from buffer 1
     phase_e(S0{}, t);
     phase_o(S0{}, t);
     phase_e(S1{}, t + 1);
@@ -294,6 +357,26 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
+  if constexpr (EK == EK_F32 || EK == EK_F32ACC) {
+    // fp32 C straight from the accumulators (16 bytes per lane = 64 contiguous bytes per row and instruction)
+    float* cb = (float*)g.C + (int64_t)ky * g.c_split;
+    w4_for<64>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
+      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
+      if (m < g.M && n < g.N) {
+        float4* dst = (float4*)(cb + (int64_t)m * g.ldc + n);
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if constexpr (EK == EK_F32ACC) {
+          const float4 o = *dst;
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *dst = v;
+      }
+      if constexpr (tt % 8 == 7) W4_FENCE();
+    });
+    return;
+  } else {
   // Staged epilogue (16-bit C): the accumulator layout gives a lane 4 consecutive n of one row, i.e. 32-byte pieces of 16 rows
   // per store instruction.  Every wave instead packs its 128x128 quadrant into its own LDS slice ([128 rows][272 B]: 256 B of
   // data + 16 B pad, conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 256
@@ -301,6 +384,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   __syncthreads();  // every wave is done with the operand tiles in LDS
   char* stage = smem + wave * W4_CSTAGE;
   const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
+  auto stage8 = [&](const float (&v)[4], auto OFF_) {
+    const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+    const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(decltype(OFF_)::value) : "memory");
+  };
   auto fill = [&](auto EPI_) {
     constexpr int EPI = decltype(EPI_)::value;
     w4_for<64>([&](auto T_) {
@@ -309,23 +397,119 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
       const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       epi_xform4<DT, EPI>(g, m, n, v);
-      const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
-      const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
-      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(i * 16 * 272 + j * 32) : "memory");
+      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
       if constexpr (tt % 8 == 7) W4_FENCE();  // (keeps hipcc from reading all 256 accumulators into VGPRs at once)
     });
   };
-  // (two variants only: every further instantiation of this 64-tile block behind a switch makes hipcc spill more of the accumulators
-  // around the merge - the bias / quick-GELU epilogues belong to the CLIP tower's K = 1024 GEMMs, which stay on the 8-wave kernel anyway)
-  if ((g.epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL) fill(integral_constant<int, MH_EPI_RESIDUAL>{});
-  else fill(integral_constant<int, 0>{});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
   const int mrow = m0 + wm * 128 + (lane >> 4);
+
+  if constexpr (EK == EK_SWIGLU) {
+    // quadrant = [64 gate | 64 up] columns n0 + 64 wn .. of ff: accumulator tiles j and j + 4 of a lane are (gate, up) of the same
+    // (token, channel).  Pass 1 stages and writes gu (both halves, rounded once); pass 2 computes act = silu(gate) * up from the fp32
+    // accumulators, stages its 64 columns in the same slice and writes them.
+    fill(integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int cq = lane & 15, gcol = n0 + wn * 64 + (cq & 7) * 8;  // channel (< ff) of this lane's 16-byte chunk
+    uint16_t* gp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + (cq < 8 ? 0 : g.sw_ff) + gcol;
+    const bool c_ok = gcol < g.sw_ff;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (c_ok && mrow + row < g.M) *(u32x4*)(gp + (int64_t)row * g.ldc) = rv[r];
+      }
+    }
+    w4_for<32>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = swiglu_fwd1(acc[i][j][e], acc[i][j + 4][e]);
+      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
+      if constexpr (tt % 4 == 3) W4_FENCE();
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned st_r2 = lds_addr_of(stage) + (unsigned)(lane >> 3) * 272 + (unsigned)(lane & 7) * 16;
+    const int arow = m0 + wm * 128 + (lane >> 3), acol = n0 + wn * 64 + (lane & 7) * 8;
+    uint16_t* ap = (uint16_t*)g.sw_out + (int64_t)arow * g.sw_ldo + acol;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 8 * 272>(rv[r], st_r2 + (unsigned)part * 64 * 272); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 64 + r * 8;
+        if (acol < g.sw_ff && arow + row < g.M) *(u32x4*)(ap + (int64_t)row * g.sw_ldo) = rv[r];
+      }
+    }
+    return;
+  } else if constexpr (EK == EK_ROPE) {
+    // the wave's 128 columns are ONE head (n0 % 256 == 0, D = 128): channel c < 64 sits in accumulator tile j = c / 16, its rotary
+    // partner c + 64 in tile j + 4 of the same lane and row -> rotate-half RoPE on the fp32 accumulators, one rounding
+    // (the v heads behind rope_cols take the same block with (cos, sin) = (1, 0): x * 1 - y * 0 is exact, and ONE store block avoids the
+    // accumulator spills hipcc produces around a merge of two)
+    const bool rot = n0 + wn * 128 < g.rope_cols;
+    w4_for<32>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + j * 16 + 4 * (lane >> 4)) * 2);
+      const float4 t01 = t4[0], t23 = t4[1];  // (c0, s0, c1, s1), (c2, s2, c3, s3)
+      const float cs[4] = {rot ? t01.x : 1.f, rot ? t01.z : 1.f, rot ? t23.x : 1.f, rot ? t23.z : 1.f};
+      const float sn[4] = {rot ? t01.y : 0.f, rot ? t01.w : 0.f, rot ? t23.y : 0.f, rot ? t23.w : 0.f};
+      float lo[4], hi[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rope_rot(acc[i][j][e], acc[i][j + 4][e], cs[e], sn[e], lo[e], hi[e]);
+      stage8(lo, integral_constant<int, i * 16 * 272 + j * 32>{});
+      stage8(hi, integral_constant<int, i * 16 * 272 + (j + 4) * 32>{});
+      if constexpr (tt % 4 == 3) W4_FENCE();
+    });
+  } else if constexpr (EK == EK_SWIGLU_BWD) {
+    fill(integral_constant<int, 0>{});  // dact, rounded to 16 bits as the unfused path stores it
+  } else {
+    // (two variants only: every further instantiation of this 64-tile block behind a switch makes hipcc spill more of the accumulators
+    // around the merge - the bias / quick-GELU epilogues belong to the CLIP tower's K = 1024 GEMMs, which stay on the 8-wave kernel anyway)
+    if ((g.epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL) fill(integral_constant<int, MH_EPI_RESIDUAL>{});
+    else fill(integral_constant<int, 0>{});
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int ncol = n0 + wn * 128 + (lane & 15) * 8;
-  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
   const bool n_ok = ncol < g.N;
-  const bool accum = (g.epi & MH_EPI_ACCUM) != 0;
+  if constexpr (EK == EK_SWIGLU_BWD) {
+    // dgu[m, n] , dgu[m, ff + n] from gu[m, n], gu[m, ff + n] and the staged dact chunk: 16-byte rows pieces in and out
+    const uint16_t* gup = (const uint16_t*)g.sw_in + (int64_t)mrow * g.sw_ldi + ncol;
+    uint16_t* dgp = (uint16_t*)g.sw_out + (int64_t)mrow * g.sw_ldo + ncol;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (n_ok && mrow + row < g.M) {
+          float d_[8], ga[8], ub[8], dg[8], du[8];
+          unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, d_);
+          unpack8<DT>(*(const uint4*)(gup + (int64_t)row * g.sw_ldi), ga);
+          unpack8<DT>(*(const uint4*)(gup + (int64_t)row * g.sw_ldi + g.sw_ff), ub);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pack8<DT>(dg);
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pack8<DT>(du);
+        }
+      }
+    }
+    return;
+  }
+  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
+  const bool accum = EK == EK_STD && (g.epi & MH_EPI_ACCUM) != 0;
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
     u32x4 rv[8];
@@ -354,6 +538,55 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
       }
     }
   }
+  }
+}
+
+template <int DT, bool AKS, bool BKS, int EK>
+__global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  w4_tile<DT, AKS, BKS, EK>(g, smem, tm, tn, (int)blockIdx.y);
+}
+
+// Grouped weight gradients: up to W4_MAX_GROUP independent TN products out_p[M_p, N_p] (+)= dy_p[T, M_p]^T x_p[T, N_p] over the SAME
+// token count in ONE launch, one block per output tile of any of them.  The CLIP tower's four Linears of a layer have 48 + 16 + 64 +
+// 64 = 192 tiles of 256^2 between them: launched one by one each needs split-K with fp32 partials to occupy the chip (0.13 of the MFMA
+// peak); together they fill 192 of 256 CUs for the whole contraction, no partials, no reduce pass.
+constexpr int W4_MAX_GROUP = 8;
+struct W4Prob {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  int64_t lda, ldb, ldc;
+  int M, N, epi, tiles_m, tiles_n, tile_end;  // tile_end: running total of tiles up to and including this problem
+};
+struct W4Group {
+  W4Prob p[W4_MAX_GROUP];
+  int n, K, gm;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void gemm_w4_grouped(W4Group G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // consecutive blocks go to consecutive XCDs: give each XCD one contiguous run of the concatenated tile list
+  const int nwg = gridDim.x, v = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < W4_MAX_GROUP - 1; ++i)
+    if (i + 1 < G.n && tile >= G.p[i].tile_end) pi = i + 1;
+  const W4Prob& P = G.p[pi];
+  const int local = tile - (pi ? G.p[pi - 1].tile_end : 0);
+  GemmArgs g{};
+  g.A = P.A; g.B = P.B; g.C = P.C; g.lda = P.lda; g.ldb = P.ldb; g.ldc = P.ldc;
+  g.M = P.M; g.N = P.N; g.K = G.K; g.epi = P.epi; g.tiles_m = P.tiles_m; g.tiles_n = P.tiles_n; g.vec_ok = 1; g.splits = 1; g.gm = G.gm;
+  const int per_group = g.gm * g.tiles_n;
+  const int group = local / per_group, first_m = group * g.gm;
+  const int gsize = min(g.tiles_m - first_m, g.gm);
+  const int in_g = local - group * per_group;
+  w4_tile<DT, true, true, EK_STD>(g, smem, first_m + in_g % gsize, in_g / gsize, 0);
 }
 
 // ---- fp8 operands (e4m3 bytes, per-row fp32 scales): the fp8 training step's NT products on the 4-wave structure ---------------------
@@ -568,31 +801,58 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
   }
 }
 
-template <int DT, bool AKS, bool BKS>
+template <int DT, bool AKS, bool BKS, int EK>
 int launch_w4(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_w4<DT, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    hipFuncSetAttribute((const void*)gemm_w4<DT, AKS, BKS, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_w4<DT, AKS, BKS>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
+  hipLaunchKernelGGL((gemm_w4<DT, AKS, BKS, EK>), dim3(g.tiles_m * g.tiles_n, g.splits > 1 ? g.splits : 1), dim3(256), W4_LDS, stream, g);
   MH_LAUNCH_CHECK();
 }
 
 }  // namespace
 
-// true when gemm_w4 can run this problem: whole K-tiles, 16-bit output through the staged epilogue (plain / bias / quick-GELU /
-// residual, optionally accumulating), 32-bit source offsets.  (The policy - where it is FASTER - lives in gemm.hip.)
-bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
+// The epilogue kind a problem needs (-1: not one gemm_w4 has).
+static int w4_kind(const GemmArgs& g) {
+  if (g.sw_mode == 1) return EK_SWIGLU;
+  if (g.sw_mode == 2) return EK_SWIGLU_BWD;
+  if (g.rope_tab) return EK_ROPE;
+  if (g.epi & MH_EPI_OUT_F32) {
+    if (g.epi == MH_EPI_OUT_F32) return EK_F32;
+    if (g.epi == (MH_EPI_OUT_F32 | MH_EPI_ACCUM) && g.splits == 1) return EK_F32ACC;
+    return -1;
+  }
   const int e = g.epi & ~MH_EPI_ACCUM;
-  const bool known = e == 0 || e == MH_EPI_RESIDUAL;
-  if (!known || (g.epi & MH_EPI_OUT_F32) || !g.vec_ok || (g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
-  if (g.K % (2 * BK) != 0 || g.splits != 1 || g.rope_tab || g.sw_mode) return false;  // an even number of K-tiles (loop unrolled by buffer)
+  return (e == 0 || e == MH_EPI_RESIDUAL) ? EK_STD : -1;
+}
+
+// true when gemm_w4 can run this problem.  K-contiguous operands need whole K-tile pairs (K % 128 == 0); a product of two K-strided
+// operands (weight gradients) takes any K.  16-bit outputs go through the staged store (16-byte row pieces), fp32 outputs straight
+// from the accumulators.  (The policy - where it is FASTER - lives in gemm.hip.)
+bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
+  const int kind = w4_kind(g);
+  if (kind < 0 || !g.vec_ok) return false;
+  const bool f32 = kind == EK_F32 || kind == EK_F32ACC;
+  if (!f32 && ((g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0))) return false;
+  if (f32 && ((g.N % 4) || (g.ldc % 4) || ((((uintptr_t)g.C) & 15u) != 0) || (g.c_split % 4))) return false;
+  if (g.splits > 1 && kind != EK_F32) return false;  // split-K writes fp32 partials
+  if (!(a_kstrided && b_kstrided) && g.K % (2 * BK) != 0) return false;
+  if (g.splits > 1) {  // even K-tile counts per split, no empty split
+    const int nkt = (g.K + 2 * BK - 1) / (2 * BK) * 2, per = ((nkt / 2 + g.splits - 1) / g.splits) * 2;
+    if ((g.splits - 1) * per >= nkt) return false;
+  }
+  if (kind == EK_ROPE && (a_kstrided || b_kstrided || g.rope_D != 128 || (g.rope_cols % 128) || g.rope_S <= 0)) return false;
+  if (kind == EK_SWIGLU && (a_kstrided || b_kstrided || (g.sw_ff % 8) || (g.sw_ldo % 8) || ((((uintptr_t)g.sw_out) & 15u) != 0))) return false;
+  if (kind == EK_SWIGLU_BWD && ((g.sw_ff % 8) || (g.sw_ldo % 8) || (g.sw_ldi % 8) || ((((uintptr_t)g.sw_out) | ((uintptr_t)g.sw_in)) & 15u) != 0 ||
+                                g.N != g.sw_ff))
+    return false;
   if (a_kstrided && (g.M % 8)) return false;
   if (b_kstrided && (g.N % 8)) return false;
   const int64_t lim = (1ll << 32) - (1 << 20);
-  const int64_t spanA = a_kstrided ? (int64_t)g.K * g.lda * 2 : (int64_t)g.M * g.lda * 2;
-  const int64_t spanB = b_kstrided ? (int64_t)g.K * g.ldb * 2 : (int64_t)g.N * g.ldb * 2;
+  const int64_t spanA = a_kstrided ? (int64_t)(g.K + 2 * BK) * g.lda * 2 : (int64_t)g.M * g.lda * 2;
+  const int64_t spanB = b_kstrided ? (int64_t)(g.K + 2 * BK) * g.ldb * 2 : (int64_t)g.N * g.ldb * 2;
   return spanA < lim && spanB < lim;
 }
 
@@ -618,18 +878,79 @@ int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream) {
   MH_LAUNCH_CHECK();
 }
 
+// (instantiated: every layout for the plain kinds; the fused kinds in the layout their call sites have)
 int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream) {
-  const int key = (dt == MH_BF16 ? 0 : 4) | (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
-  switch (key) {
-    case 0: return launch_w4<MH_BF16, false, false>(g, stream);
-    case 1: return launch_w4<MH_BF16, false, true>(g, stream);
-    case 2: return launch_w4<MH_BF16, true, false>(g, stream);
-    case 3: return launch_w4<MH_BF16, true, true>(g, stream);
-    case 4: return launch_w4<MH_F16, false, false>(g, stream);
-    case 5: return launch_w4<MH_F16, false, true>(g, stream);
-    case 6: return launch_w4<MH_F16, true, false>(g, stream);
-    default: return launch_w4<MH_F16, true, true>(g, stream);
+  const int kind = w4_kind(g);
+  const int lay = (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
+#define W4_GO(DT_, AKS_, BKS_, EK_) return launch_w4<DT_, AKS_, BKS_, EK_>(g, stream)
+#define W4_LAYOUTS(DT_, EK_)                                                     \
+  switch (lay) {                                                                 \
+    case 0: W4_GO(DT_, false, false, EK_);                                       \
+    case 1: W4_GO(DT_, false, true, EK_);                                        \
+    case 2: W4_GO(DT_, true, false, EK_);                                        \
+    default: W4_GO(DT_, true, true, EK_);                                        \
   }
+  if (dt == MH_BF16) {
+    switch (kind) {
+      case EK_STD: W4_LAYOUTS(MH_BF16, EK_STD)
+      case EK_F32: if (lay == 0) W4_GO(MH_BF16, false, false, EK_F32); if (lay == 3) W4_GO(MH_BF16, true, true, EK_F32); break;
+      case EK_F32ACC: if (lay == 0) W4_GO(MH_BF16, false, false, EK_F32ACC); break;
+      case EK_ROPE: if (lay == 0) W4_GO(MH_BF16, false, false, EK_ROPE); break;
+      case EK_SWIGLU: if (lay == 0) W4_GO(MH_BF16, false, false, EK_SWIGLU); break;
+      case EK_SWIGLU_BWD: if (lay == 1) W4_GO(MH_BF16, false, true, EK_SWIGLU_BWD); break;
+      default: break;
+    }
+  } else {
+    switch (kind) {
+      case EK_STD: W4_LAYOUTS(MH_F16, EK_STD)
+      case EK_F32: if (lay == 0) W4_GO(MH_F16, false, false, EK_F32); if (lay == 3) W4_GO(MH_F16, true, true, EK_F32); break;
+      case EK_F32ACC: if (lay == 0) W4_GO(MH_F16, false, false, EK_F32ACC); break;
+      case EK_ROPE: if (lay == 0) W4_GO(MH_F16, false, false, EK_ROPE); break;
+      case EK_SWIGLU: if (lay == 0) W4_GO(MH_F16, false, false, EK_SWIGLU); break;
+      case EK_SWIGLU_BWD: if (lay == 1) W4_GO(MH_F16, false, true, EK_SWIGLU_BWD); break;
+      default: break;
+    }
+  }
+#undef W4_LAYOUTS
+#undef W4_GO
+  return MH_ERR_ARG;
+}
+// layouts each fused / fp32 kind is instantiated for (w4_can_run is necessary, this is the second condition)
+bool w4_has_kernel(const GemmArgs& g, int a_kstrided, int b_kstrided) {
+  const int kind = w4_kind(g), lay = (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
+  switch (kind) {
+    case EK_STD: return true;
+    case EK_F32: return lay == 0 || lay == 3;
+    case EK_F32ACC: case EK_ROPE: case EK_SWIGLU: return lay == 0;
+    case EK_SWIGLU_BWD: return lay == 1;
+    default: return false;
+  }
+}
+
+// grouped weight gradients (see gemm_w4_grouped): n <= W4_MAX_GROUP problems over the same K
+int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStream_t stream) {
+  if (n < 1 || n > W4_MAX_GROUP) return MH_ERR_ARG;
+  W4Group G{};
+  G.n = n; G.K = probs[0].K; G.gm = gm;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& g = probs[i];
+    if (g.K != G.K || !w4_can_run(g, 1, 1) || w4_kind(g) != EK_STD) return MH_ERR_ARG;
+    W4Prob& P = G.p[i];
+    P.A = g.A; P.B = g.B; P.C = g.C; P.lda = g.lda; P.ldb = g.ldb; P.ldc = g.ldc; P.M = g.M; P.N = g.N; P.epi = g.epi;
+    P.tiles_m = g.tiles_m; P.tiles_n = g.tiles_n;
+    total += g.tiles_m * g.tiles_n;
+    P.tile_end = total;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_w4_grouped<MH_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    hipFuncSetAttribute((const void*)gemm_w4_grouped<MH_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    attr_set = true;
+  }
+  if (dt == MH_BF16) hipLaunchKernelGGL((gemm_w4_grouped<MH_BF16>), dim3(total), dim3(256), W4_LDS, stream, G);
+  else hipLaunchKernelGGL((gemm_w4_grouped<MH_F16>), dim3(total), dim3(256), W4_LDS, stream, G);
+  MH_LAUNCH_CHECK();
 }
 
 }  // namespace mhgemm

@@ -264,24 +264,36 @@ class HipEngine:
         Tpad = _ru(T, 64)
         p = W.p
         acc = not fresh
-        # fc2
+        # The four weight gradients of the layer are issued as ONE grouped launch (O.wgrad_tn_grouped: 48 + 16 + 64 + 64 output tiles of
+        # 256^2 for ViT-L fill the chip together for the whole 27 696-token contraction; one by one each needed split-K with fp32
+        # partials).  Its operands must therefore all be alive at one point: the LayerNorm backward that used to accumulate dx2 IN PLACE
+        # into dy gets a copy to accumulate into (57 MB at cfg 3), the grouped launch sits before the last in-place accumulation.
+        grouped = O.wgrad_group_pays(T, [(dy.shape[1], a.shape[1]), (f1.shape[1], h2.shape[1]), (dy.shape[1], o.shape[1]), (qkv.shape[1], h1.shape[1])])
         da = O.gemm_nt(dy, W.w2, b_t=True)
-        self._wgrad(dy, a, A.gview(p + "mlp.fc2.weight"), fresh, Tpad)
+        if not grouped:
+            self._wgrad(dy, a, A.gview(p + "mlp.fc2.weight"), fresh, Tpad)
         O.colsum(dy, A.gview(p + "mlp.fc2.bias"), accumulate=acc)
         df1 = O.quick_gelu_bwd(f1, da)
         dh2 = O.gemm_nt(df1, W.w1, b_t=True)
-        self._wgrad(df1, h2, A.gview(p + "mlp.fc1.weight"), fresh, Tpad)
+        if not grouped:
+            self._wgrad(df1, h2, A.gview(p + "mlp.fc1.weight"), fresh, Tpad)
         O.colsum(df1, A.gview(p + "mlp.fc1.bias"), accumulate=acc)
-        dx2 = O.layernorm_bwd(x2, W.ln2w, dh2, eps, dx=dy, accumulate_dx=True, dw_out=A.gview(p + "layer_norm2.weight"),
-                              db_out=A.gview(p + "layer_norm2.bias"), accumulate=acc)
+        dx2 = O.layernorm_bwd(x2, W.ln2w, dh2, eps, dx=O.copy2d(dy, torch.empty_like(dy)) if grouped else dy, accumulate_dx=True,
+                              dw_out=A.gview(p + "layer_norm2.weight"), db_out=A.gview(p + "layer_norm2.bias"), accumulate=acc)
         do = O.gemm_nt(dx2, W.wo, b_t=True)
-        self._wgrad(dx2, o, A.gview(p + "self_attn.out_proj.weight"), fresh, Tpad)
+        if not grouped:
+            self._wgrad(dx2, o, A.gview(p + "self_attn.out_proj.weight"), fresh, Tpad)
         O.colsum(dx2, A.gview(p + "self_attn.out_proj.bias"), accumulate=acc)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
         O.attn_bwd2(q, k, v, o, do, lse, N, S, H, D, False, dq=dqkv[:, :vd], dk=dqkv[:, vd:2 * vd], dv=dqkv[:, 2 * vd:])
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
-        self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd)), fresh, Tpad)
+        gqkv = A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * vd, vd))
+        if grouped:
+            O.wgrad_tn_grouped([(dy, a, A.gview(p + "mlp.fc2.weight")), (df1, h2, A.gview(p + "mlp.fc1.weight")),
+                                (dx2, o, A.gview(p + "self_attn.out_proj.weight")), (dqkv, h1, gqkv)], accum=acc)
+        else:
+            self._wgrad(dqkv, h1, gqkv, fresh, Tpad)
         O.colsum(dqkv, A.gspan(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", (3 * vd,)), accumulate=acc)
         dx = O.layernorm_bwd(x, W.ln1w, dh1, eps, dx=dx2, accumulate_dx=True, dw_out=A.gview(p + "layer_norm1.weight"),
                              db_out=A.gview(p + "layer_norm1.bias"), accumulate=acc)

@@ -393,6 +393,46 @@ def wgrad_tn(dy, x, out, accum):
     return out
 
 
+class _WgradProblem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("accumulate", C.c_int), ("reserved", C.c_int)]
+
+
+WGRAD_GROUPED = os.environ.get("MH_WGRAD_GROUPED", "1") != "0"  # A/B switch
+WGRAD_GROUPED_MIN_TILES = 32  # below that (the tiny test models) the per-problem launches are used unless forced
+
+
+def wgrad_group_pays(T, shapes):
+    """Launch-plan predicate of wgrad_tn_grouped for problems of shapes [(M_p, N_p)] over T tokens (host arithmetic only)."""
+    tiles = sum(((m + 255) // 256) * ((n + 255) // 256) for m, n in shapes)
+    return WGRAD_GROUPED and len(shapes) <= 8 and T >= 1024 and tiles >= WGRAD_GROUPED_MIN_TILES and all(m % 8 == 0 and n % 8 == 0 for m, n in shapes)
+
+
+def wgrad_tn_grouped(problems, accum, force=False):
+    """[(dy [T, M_p], x [T, N_p], out [M_p, N_p])] -> out_p (+)= dy_p^T x_p for all p in ONE launch (mh_wgrad_grouped: one block per
+    256 x 256 tile of any problem, whole contraction, no fp32 partials); falls back to wgrad_tn per problem when the group is too small
+    to matter or a problem does not meet the kernel's layout conditions."""
+    T = problems[0][0].shape[0]
+    ok = len(problems) <= 8 and all(dy.shape[0] == T and x.shape[0] == T and dy.dtype == x.dtype == out.dtype and
+                                    out.dtype in (torch.bfloat16, torch.float16) for dy, x, out in problems)
+    if ok and (force or wgrad_group_pays(T, [(dy.shape[1], x.shape[1]) for dy, x, _ in problems])):
+        arr = (_WgradProblem * len(problems))()
+        flops = nbytes = 0.0
+        for i, (dy, x, out) in enumerate(problems):
+            arr[i] = _WgradProblem(dy.data_ptr(), _rowmajor(dy), x.data_ptr(), _rowmajor(x), out.data_ptr(), _rowmajor(out), dy.shape[1], x.shape[1],
+                                   int(accum), 0)
+            flops += 2.0 * dy.shape[1] * x.shape[1] * T
+            nbytes += 2.0 * (dy.shape[1] * T + x.shape[1] * T + dy.shape[1] * x.shape[1])
+        with _timed("gemm_nt", flops, nbytes):
+            rc = L.lib().mh_wgrad_grouped(arr, i32(len(problems)), i32(T), i32(dt_of(problems[0][0])), _stream())
+        if rc == 0:
+            return
+        if rc != -4:  # MH_ERR_SHAPE = "not for this kernel": per-problem launches below; anything else is an error
+            L.check(rc, "mh_wgrad_grouped")
+    for dy, x, out in problems:
+        wgrad_tn(dy, x, out, accum)
+
+
 def gemm_nt_rope(a, b, table, S, H, D, out=None):
     """qkv = a @ b^T with RoPE applied to the q and k heads in the GEMM epilogue (b = fused [q; k; v] weight, 3*H*D rows)."""
     M, K = a.shape

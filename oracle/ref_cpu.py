@@ -41,13 +41,15 @@ IGNORE_INDEX = -100  # mmgpt/utils/constants.py:7
 # every Linear (weights from merlin_amd/weights.py are exactly representable), the rotated q / k, v and the softmax probabilities of
 # both attentions - and, with stream=True, the residual streams after every add as well.  Accumulation, norms, softmax, RoPE, SwiGLU
 # stay fp32.  The logits error of that run against the reference golden is the FLOOR of any single-pass 16-bit-operand implementation:
-# what the HIP path's own error is held against.
+# what the HIP path's own error is held against.  outputs=True additionally rounds the GEMM outputs the HIP path STORES in 16 bits
+# before an element-wise op consumes them (q | k before the rotation, gate | up before SwiGLU: the fused epilogues work on the rounded
+# values so that fused and unfused kernels agree bit for bit) - the storage-format model of the HIP path itself.
 _ROUND = None
 
 
 class rounding:
-    def __init__(self, dtype, stream=False):
-        self.cfg = (dtype, bool(stream))
+    def __init__(self, dtype, stream=False, outputs=False):
+        self.cfg = (dtype, bool(stream), bool(outputs))
 
     def __enter__(self):
         global _ROUND
@@ -66,6 +68,11 @@ def _q(x):
 def _qs(x):
     """a residual stream"""
     return x if (_ROUND is None or not _ROUND[1]) else x.to(_ROUND[0]).to(x.dtype)
+
+
+def _qo(x):
+    """a GEMM output stored in 16 bits ahead of a fused element-wise op"""
+    return x if (_ROUND is None or not _ROUND[2]) else x.to(_ROUND[0]).to(x.dtype)
 
 
 def _linear(x, w, b=None):
@@ -171,11 +178,12 @@ def clip_tower_forward(P: dict, cfg: OracleConfig, pixels: torch.Tensor) -> torc
     N = pixels.shape[0]
     vd, nh = cfg.v_hidden_size, cfg.v_num_attention_heads
     hd = vd // nh
-    x = F.conv2d(_q(pixels), P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size)
+    x = _qo(F.conv2d(_q(pixels), P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size))
     x = x.flatten(2).transpose(1, 2)  # [N, grid^2, vd]
     cls = P[VT + "embeddings.class_embedding"].expand(N, 1, -1)
-    x = torch.cat([cls, x], dim=1) + P[VT + "embeddings.position_embedding.weight"][None]
-    x = _qs(F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps))
+    x = _qo(torch.cat([cls, x], dim=1) + P[VT + "embeddings.position_embedding.weight"][None])
+    # (the HIP path's tower starts from 16-bit tensors - patch projection, assembled embeddings, pre-LN output - whatever its stream holds later)
+    x = _qo(_qs(F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps)))
     for i in range(cfg.v_layers_used):
         p = VT + f"encoder.layers.{i}."
         r = x
@@ -263,8 +271,8 @@ def rotate_half(x):
 def llama_attention(P, cfg, prefix, h, cos, sin, add_mask):
     B, S, d = h.shape
     nh, hd = cfg.num_attention_heads, cfg.head_dim
-    q = _linear(h, P[prefix + "q_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
-    k = _linear(h, P[prefix + "k_proj.weight"]).view(B, S, nh, hd).transpose(1, 2)
+    q = _qo(_linear(h, P[prefix + "q_proj.weight"])).view(B, S, nh, hd).transpose(1, 2)
+    k = _qo(_linear(h, P[prefix + "k_proj.weight"])).view(B, S, nh, hd).transpose(1, 2)
     v = _q(_linear(h, P[prefix + "v_proj.weight"])).view(B, S, nh, hd).transpose(1, 2)
     q = _q(q * cos + rotate_half(q) * sin)
     k = _q(k * cos + rotate_half(k) * sin)
@@ -287,7 +295,7 @@ def llama_forward(P: dict, cfg: OracleConfig, x: torch.Tensor, attention_mask=No
         p = f"model.layers.{i}."
         x = _qs(x + llama_attention(P, cfg, p + "self_attn.", rms_norm(x, P[p + "input_layernorm.weight"], cfg.rms_norm_eps), cos, sin, add_mask))
         h = rms_norm(x, P[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-        h = F.silu(_linear(h, P[p + "mlp.gate_proj.weight"])) * _linear(h, P[p + "mlp.up_proj.weight"])
+        h = F.silu(_qo(_linear(h, P[p + "mlp.gate_proj.weight"]))) * _qo(_linear(h, P[p + "mlp.up_proj.weight"]))
         x = _qs(x + _linear(h, P[p + "mlp.down_proj.weight"]))
     return rms_norm(x, P["model.norm.weight"], cfg.rms_norm_eps)
 
@@ -302,7 +310,7 @@ def forward(P: dict, cfg: OracleConfig, input_ids, attention_mask=None, labels=N
     """MMGPTLlamaForCausalLM.forward (llama_mmgpt.py:53-112).  Returns (loss|None, logits)."""
     if images is not None and input_ids.shape[1] != 1:
         feats = encode_images(P, cfg, images)
-        x = _qs(splice_image_features(P, cfg, input_ids, feats))
+        x = _qo(_qs(splice_image_features(P, cfg, input_ids, feats)))  # (projector output / embedding rows: 16-bit before the decoder's stream)
     else:
         x = F.embedding(input_ids, P["model.embed_tokens.weight"])
     h = llama_forward(P, cfg, x, attention_mask)

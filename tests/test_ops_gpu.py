@@ -807,10 +807,15 @@ def test_gemm_with_fused_rope_is_bit_identical_to_gemm_then_rope(ops, dtype, B, 
     finally:
         ops.gemm_force_kernel(0)
     ops.rope_qk_(ref, tab, S, H, D)
-    got = ops.gemm_nt_rope(x, w, tab, S, H, D)
-    assert torch.equal(got, ref)
-    for _ in range(2):
-        assert torch.equal(ops.gemm_nt_rope(x, w, tab, S, H, D), got)
+    try:
+        ops.gemm_force_kernel(256)  # (the 4-wave kernel rotates the fp32 accumulators instead: tests/test_gemm_w4_gpu.py)
+        got = ops.gemm_nt_rope(x, w, tab, S, H, D)
+        assert torch.equal(got, ref)
+        for _ in range(2):
+            assert torch.equal(ops.gemm_nt_rope(x, w, tab, S, H, D), got)
+    finally:
+        ops.gemm_force_kernel(0)
+    assert relerr(ops.gemm_nt_rope(x, w, tab, S, H, D), ref.float()) < 3 * EPS16[dtype]  # whichever kernel the dispatcher picks
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -845,15 +850,25 @@ def test_gemm_with_fused_swiglu_is_bit_identical_to_unfused(ops, dtype, M, ff, K
     finally:
         ops.gemm_force_kernel(0)
     act_ref = ops.swiglu_fwd(gu_ref)
-    gu, act = ops.gemm_swiglu_fwd(x, wgu)
-    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
-    # backward: dy [M, d], wd [d, ff]
-    d = K
-    dy, wd = rnd(M, d, dtype=dtype, seed=2, scale=0.5), rnd(d, ff, dtype=dtype, seed=3, scale=0.5)
-    dact = ops.gemm_nt(dy, wd, b_t=True)
-    dgu_ref = ops.swiglu_bwd(gu_ref, dact)
-    dgu = ops.gemm_swiglu_bwd(dy, wd, gu_ref)
-    assert torch.equal(dgu, dgu_ref)
+    # (the 8-wave kernel's staged form: it gates the ROUNDED 16-bit tile, hence bit-identity with the unfused kernels; the 4-wave kernel's
+    # form gates the fp32 accumulators - one rounding less - and is held to fp32 in tests/test_gemm_w4_gpu.py)
+    try:
+        ops.gemm_force_kernel(256)
+        gu, act = ops.gemm_swiglu_fwd(x, wgu)
+        assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+        # backward: dy [M, d], wd [d, ff]
+        d = K
+        dy, wd = rnd(M, d, dtype=dtype, seed=2, scale=0.5), rnd(d, ff, dtype=dtype, seed=3, scale=0.5)
+        dact = ops.gemm_nt(dy, wd, b_t=True)
+        dgu_ref = ops.swiglu_bwd(gu_ref, dact)
+        dgu = ops.gemm_swiglu_bwd(dy, wd, gu_ref)
+        assert torch.equal(dgu, dgu_ref)
+    finally:
+        ops.gemm_force_kernel(0)
+    # whichever kernel the dispatcher picks for this shape: within one rounding of the unfused result
+    gu2, act2 = ops.gemm_swiglu_fwd(x, wgu)
+    assert relerr(gu2, gu_ref.float()) < 2 * EPS16[dtype] and relerr(act2, act_ref.float()) < 3 * EPS16[dtype]
+    assert relerr(ops.gemm_swiglu_bwd(dy, wd, gu_ref), dgu_ref.float()) < 3 * EPS16[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -141,6 +141,15 @@ int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, in
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,
                    void* stream);
 
+/* CLIP MLP (HF CLIPMLP fc1 -> quick_gelu -> fc2, called from clip_encoder.py:79): quick-GELU in the GEMM's store phase.  Forward: f1 [M, N] =
+ * x [M, K] W1[N, K]^T + b1 and a = f1 * sigmoid(1.702 f1) (both stored: the backward needs f1).  Backward: df1 [M, N] = quick_gelu'(f1) * (dy [M, K] w2[K, N])
+ * with w2 = fc2.weight read K-strided and dy w2 never stored.  Element maths on the rounded 16-bit tile: bit-identical to mh_gemm + mh_quick_gelu_fwd / _bwd.
+ * N, ldf, lda_out, lddf multiples of 8, 16-byte aligned outputs. */
+int mh_gemm_gelu_fwd(const void* x, int64_t ldx, const void* w1, int64_t ldw, const void* bias, void* f1, int64_t ldf, void* a, int64_t lda_out,
+                     int M, int N, int K, int dt, void* stream);
+int mh_gemm_gelu_bwd(const void* dy, int64_t lddy, const void* w2, int64_t ldw, const void* f1, int64_t ldf, void* df1, int64_t lddf,
+                     int M, int N, int K, int dt, void* stream);
+
 /* Several weight gradients over the SAME token count in one launch: out_p[M_p, N_p] (+)= dy_p[T, M_p]^T x_p[T, N_p] for p < n <= 8, both
  * operands as they lie in memory (K-strided), any T (rows >= T read as zeros), 16-bit outputs.  One block per 256 x 256 output tile of
  * any of the problems: the four Linears of a CLIP encoder layer (48 + 16 + 64 + 64 tiles; autograd of HF CLIPEncoderLayer,

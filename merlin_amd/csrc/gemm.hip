@@ -395,6 +395,25 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
 }
 
+// quick-GELU in the GEMM store phase (CLIP MLP; HF CLIPMLP `fc1 -> quick_gelu -> fc2`): forward f1 = x W1^T + b1 AND a = quick_gelu(f1) from one
+// launch; backward df1 = quick_gelu'(f1) * (dY W2) with dY W2 never stored.  Both work on the ROUNDED 16-bit tile: bit-identical to mh_gemm followed
+// by mh_quick_gelu_fwd / _bwd.
+extern "C" int mh_gemm_gelu_fwd(const void* x, int64_t ldx, const void* w1, int64_t ldw, const void* bias, void* f1, int64_t ldf, void* a, int64_t lda_out,
+                                int M, int N, int K, int dt, void* stream) {
+  if (!bias || !f1 || !a || (N & 7) || (ldf & 7) || (lda_out & 7) || ((((uintptr_t)f1) | ((uintptr_t)a)) & 15u) || (((uintptr_t)bias) & 7u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 3; r.sw_out = a; r.sw_ldo = lda_out;
+  return gemm_impl(x, ldx, 0, w1, ldw, 0, f1, ldf, bias, nullptr, 0, M, N, K, dt, MH_EPI_BIAS, 1, 0, stream, r);
+}
+extern "C" int mh_gemm_gelu_bwd(const void* dy, int64_t lddy, const void* w2, int64_t ldw, const void* f1, int64_t ldf, void* df1, int64_t lddf,
+                                int M, int N, int K, int dt, void* stream) {
+  // dy [M, K = d], w2 = fc2.weight [d, N = ff] read K-strided, f1 / df1 [M, N]
+  if (!f1 || !df1 || (N & 7) || (ldf & 7) || (lddf & 7) || ((((uintptr_t)f1) | ((uintptr_t)df1)) & 15u)) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 4; r.sw_out = df1; r.sw_ldo = lddf; r.sw_in = f1; r.sw_ldi = ldf;
+  return gemm_impl(dy, lddy, 0, w2, ldw, 1, df1, lddf, nullptr, nullptr, 0, M, N, K, dt, 0, 1, 0, stream, r);
+}
+
 extern "C" int mh_wgrad_grouped(const MhWgradProblem* pr, int n, int T, int dt, void* stream) {
   if (!pr || n < 1 || n > 8 || T <= 0) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;

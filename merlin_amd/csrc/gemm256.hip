@@ -475,6 +475,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmArgs g) {  // (g by va
             *(uint4*)(dgu + g.sw_ff + ncol) = pack8<DT>(du);
           }
         }
+      } else if (g.sw_mode == 3) {
+        // fused quick-GELU forward (CLIP MLP, fc1): the staged tile is f1 = x W1^T + b1 rounded to 16 bits; C = f1 (the backward needs it) and
+        // sw_out = a = f1 * sigmoid(1.702 f1) from the rounded values, exactly as mh_quick_gelu_fwd computes it from the stored tensor
+        if (n_ok) {
+#pragma unroll 2
+          for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 5);
+            if (mh + row >= g.M) continue;
+            const uint4 val = *(const uint4*)(cst + row * C_ROW + (tid & 31) * 16);
+            *(uint4*)((uint16_t*)g.C + (int64_t)(mh + row) * g.ldc + ncol) = val;
+            float x[8];
+            unpack8<DT>(val, x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = x[k] * sigmoidf_(1.702f * x[k]);
+            *(uint4*)((uint16_t*)g.sw_out + (int64_t)(mh + row) * g.sw_ldo + ncol) = pack8<DT>(x);
+          }
+        }
+      } else if (g.sw_mode == 4) {
+        // fused quick-GELU backward (fc2 dgrad): the staged tile is da = dY W2 rounded to 16 bits and never stored; sw_out = df1 =
+        // da * s * (1 + 1.702 f1 (1 - s)), s = sigmoid(1.702 f1), with f1 = sw_in - mh_quick_gelu_bwd's arithmetic on the same values
+        if (n_ok) {
+#pragma unroll 2
+          for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 5);
+            if (mh + row >= g.M) continue;
+            float z[8], x[8];
+            unpack8<DT>(*(const uint4*)(cst + row * C_ROW + (tid & 31) * 16), z);
+            unpack8<DT>(*(const uint4*)((const uint16_t*)g.sw_in + (int64_t)(mh + row) * g.sw_ldi + ncol), x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float sg = sigmoidf_(1.702f * x[k]);
+              x[k] = z[k] * sg * (1.0f + 1.702f * x[k] * (1.0f - sg));
+            }
+            *(uint4*)((uint16_t*)g.sw_out + (int64_t)(mh + row) * g.sw_ldo + ncol) = pack8<DT>(x);
+          }
+        }
       } else if (g.rope_tab && n0 < g.rope_cols) {
         // fused RoPE (llama_flash_attn_monkey_patch.py:56-59): the tile holds whole heads (256 % D == 0, rope_cols % D == 0), so the
         // thread that owns a low-half 8-channel chunk also reads its partner chunk D/2 channels later from the same LDS row and

@@ -816,6 +816,7 @@ int launch_w4(const GemmArgs& g, hipStream_t stream) {
 
 // The epilogue kind a problem needs (-1: not one gemm_w4 has).
 static int w4_kind(const GemmArgs& g) {
+  if (g.sw_mode > 2) return -1;  // (quick-GELU forms: 8-wave kernel only)
   if (g.sw_mode == 1) return EK_SWIGLU;
   if (g.sw_mode == 2) return EK_SWIGLU_BWD;
   if (g.rope_tab) return EK_ROPE;

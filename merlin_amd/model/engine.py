@@ -243,13 +243,19 @@ class HipEngine:
         x2 = O.gemm_nt(o, W.wo, bias=W.bo, resid=x)
         h2 = O.layernorm_fwd(x2, W.ln2w, W.ln2b, eps)
         if keep:
-            f1 = O.gemm_nt(h2, W.w1, bias=W.b1)
-            a = O.quick_gelu_fwd(f1)
+            f1, a = self._fc1_gelu(h2, W)  # f1 (kept for the backward) and quick_gelu(f1) from one launch
         else:
             f1 = None
             a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
         y = O.gemm_nt(a, W.w2, bias=W.b2, resid=x2)
         return y, ((h1, qkv, o, lse, x2, h2, f1, a) if keep else None)
+
+    @staticmethod
+    def _fc1_gelu(h2, W):
+        if W.w1.shape[0] % 8 == 0 and h2.shape[1] % 64 == 0:
+            return O.gemm_gelu_fwd(h2, W.w1, W.b1)
+        f1 = O.gemm_nt(h2, W.w1, bias=W.b1)
+        return f1, O.quick_gelu_fwd(f1)
 
     def _vit_layer_bwd(self, W, x, dy, N, S, vc, saved, fresh):
         A = self.arena
@@ -269,11 +275,13 @@ class HipEngine:
         # partials).  Its operands must therefore all be alive at one point: the LayerNorm backward that used to accumulate dx2 IN PLACE
         # into dy gets a copy to accumulate into (57 MB at cfg 3), the grouped launch sits before the last in-place accumulation.
         grouped = O.wgrad_group_pays(T, [(dy.shape[1], a.shape[1]), (f1.shape[1], h2.shape[1]), (dy.shape[1], o.shape[1]), (qkv.shape[1], h1.shape[1])])
-        da = O.gemm_nt(dy, W.w2, b_t=True)
+        if f1.shape[1] % 8 == 0 and dy.shape[1] % 64 == 0:
+            df1 = O.gemm_gelu_bwd(dy, W.w2, f1)  # quick-GELU backward in the fc2 dgrad's store phase (dy W2 never stored)
+        else:
+            df1 = O.quick_gelu_bwd(f1, O.gemm_nt(dy, W.w2, b_t=True))
         if not grouped:
             self._wgrad(dy, a, A.gview(p + "mlp.fc2.weight"), fresh, Tpad)
         O.colsum(dy, A.gview(p + "mlp.fc2.bias"), accumulate=acc)
-        df1 = O.quick_gelu_bwd(f1, da)
         dh2 = O.gemm_nt(df1, W.w1, b_t=True)
         if not grouped:
             self._wgrad(df1, h2, A.gview(p + "mlp.fc1.weight"), fresh, Tpad)
@@ -426,7 +434,7 @@ class HipEngine:
         if r32:
             x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
             for i in range(L):
-                x16, sv = self._vit_layer_fwd_r32(self.vit[i], x32, N, S, vc, keep=train_tower and self.save_activations)
+                x16, sv = self._vit_layer_fwd_r32(self.vit[i], x32, N, S, vc, keep=train_tower and self.save_activations, need_x16=train_tower)
                 if train_tower:
                     xs.append(x16)
                 saves.append(sv)
@@ -555,13 +563,13 @@ class HipEngine:
         y = O.gemm_nt(act, W.wd, resid=x2)
         return y, ((h1, qkv, o, lse, x2, h2, gu, act, packed) if keep else None)
 
-    def _llama_layer_fwd_r32(self, W, x32, B, S, lens, keep, kv_out=None, unpad=None):
+    def _llama_layer_fwd_r32(self, W, x32, B, S, lens, keep, kv_out=None, unpad=None, need_x16=True):
         """_llama_layer_fwd on the fp32 residual stream: x32 [T, d] is updated IN PLACE; returns (x16 = the 16-bit copy of the layer
         input for the backward, saved activations | None)."""
         cfg = self.model.config
         H, D = cfg.num_attention_heads, head_dim_of(cfg)
         eps = cfg.rms_norm_eps
-        h1, x16 = O.norm_fwd_f32in(x32, W.ln1, eps, want_x16=True)
+        h1, x16 = O.norm_fwd_f32in(x32, W.ln1, eps, want_x16=need_x16)  # (the 16-bit copy of the layer input is the BACKWARD's: not written without one)
         qkv = O.gemm_nt_rope(h1, W.wqkv, self.rope, S, H, D)
         o, lse, packed = self._attn_fwd(qkv, B, S, H, D, lens, unpad, kv_out)
         O.gemm_nt(o, W.wo, out=x32, accum=True)           # x += o Wo^T, fp32 read-modify-write in the GEMM epilogue
@@ -570,20 +578,19 @@ class HipEngine:
         O.gemm_nt(act, W.wd, out=x32, accum=True)         # x += act Wd^T
         return x16, ((h1, qkv, o, lse, x2_16, h2, gu, act, packed) if keep else None)
 
-    def _vit_layer_fwd_r32(self, W, x32, N, S, vc, keep):
+    def _vit_layer_fwd_r32(self, W, x32, N, S, vc, keep, need_x16=True):
         H = vc.num_attention_heads
         vd = vc.hidden_size
         D = vd // H
         eps = vc.layer_norm_eps
-        h1, x16 = O.norm_fwd_f32in(x32, W.ln1w, eps, b=W.ln1b, want_x16=True)
+        h1, x16 = O.norm_fwd_f32in(x32, W.ln1w, eps, b=W.ln1b, want_x16=need_x16)
         qkv = O.gemm_nt(h1, W.wqkv, bias=W.bqkv)
         q, k, v = qkv[:, :vd], qkv[:, vd:2 * vd], qkv[:, 2 * vd:]
         o, lse = O.attn_fwd2(q, k, v, N, S, H, D, causal=False)
         O.gemm_nt(o, W.wo, bias=W.bo, out=x32, accum=True)
         h2, x2_16 = O.norm_fwd_f32in(x32, W.ln2w, eps, b=W.ln2b, want_x16=keep)
         if keep:
-            f1 = O.gemm_nt(h2, W.w1, bias=W.b1)
-            a = O.quick_gelu_fwd(f1)
+            f1, a = self._fc1_gelu(h2, W)
         else:
             f1 = None
             a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
@@ -941,7 +948,8 @@ class HipEngine:
             x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
             for li, W in enumerate(self.llama):
                 x16, sv = self._llama_layer_fwd_r32(W, x32, B, S, lens, keep=want_grad and self.save_activations,
-                                                    kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad)
+                                                    kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad,
+                                                    need_x16=want_grad)
                 if want_grad:
                     xs.append(x16)
                 saves.append(sv)

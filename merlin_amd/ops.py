@@ -470,6 +470,30 @@ def gemm_swiglu_bwd(dy, wd, gu):
     return dgu
 
 
+def gemm_gelu_fwd(x, w1, bias):
+    """(f1, a) = (x @ w1^T + bias, quick_gelu(f1)) from ONE GEMM launch (CLIP MLP fc1; the backward needs f1, fc2 needs a)."""
+    M, K = x.shape
+    N = w1.shape[0]
+    f1 = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    a = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)):
+        L.check(L.lib().mh_gemm_gelu_fwd(p(x), i64(_rowmajor(x)), p(w1), i64(_rowmajor(w1)), p(bias), p(f1), i64(N), p(a), i64(N), i32(M), i32(N), i32(K),
+                                         i32(dt_of(x)), _stream()), "mh_gemm_gelu_fwd")
+    return f1, a
+
+
+def gemm_gelu_bwd(dy, w2, f1):
+    """df1 = quick_gelu'(f1) * (dy @ w2) with the GELU backward in the dgrad GEMM's store phase (dy @ w2 never stored); w2 = fc2.weight [d, ff]."""
+    M, K = dy.shape
+    N = w2.shape[1]
+    assert w2.shape[0] == K and f1.shape == (M, N)
+    df1 = torch.empty_like(f1)
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)):
+        L.check(L.lib().mh_gemm_gelu_bwd(p(dy), i64(_rowmajor(dy)), p(w2), i64(_rowmajor(w2)), p(f1), i64(_rowmajor(f1)), p(df1), i64(_rowmajor(df1)),
+                                         i32(M), i32(N), i32(K), i32(dt_of(dy)), _stream()), "mh_gemm_gelu_bwd")
+    return df1
+
+
 def quant_fp8_rows(x, k_pad=None):
     """x [R, K] (16-bit) -> (q uint8 [R, K] OCP e4m3, scales fp32 [R]): one scale per row.  k_pad > K: q is [R, k_pad], zero behind K."""
     R, K = x.shape

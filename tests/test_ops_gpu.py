@@ -1088,3 +1088,30 @@ def test_skinny_gemm_split_k_with_epilogues(ops, dtype, M, N, K, monkeypatch):
         assert relerr(split[k], w) < tol, k
         assert relerr(split[k], one[k].float()) < 2 * EPS16[dtype], (k, "vs the one-pass kernel")
         assert torch.equal(split[k], again[k]), (k, "deterministic")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,vd,vff", [(1154, 128, 256), (27696, 1024, 4096), (600, 192, 520)])
+def test_gemm_with_fused_quick_gelu_is_bit_identical_to_unfused(ops, dtype, T, vd, vff):
+    """CLIP MLP: fc1 + bias with quick-GELU in the store phase emitting BOTH f1 and a (mh_gemm_gelu_fwd), and the fc2 dgrad with the
+    quick-GELU backward in its store phase (mh_gemm_gelu_bwd: dy W2 never stored) against mh_gemm + the stand-alone element-wise
+    kernels on the stored 16-bit tensors: bit for bit (both work on the rounded tile)."""
+    h2, w1, b1 = rnd(T, vd, dtype=dtype), rnd(vff, vd, dtype=dtype, seed=1, scale=0.3), rnd(vff, dtype=dtype, seed=2)
+    try:
+        ops.gemm_force_kernel(256)  # same kernel, same summation order for the reference
+        f1_ref = ops.gemm_nt(h2, w1, bias=b1)
+        a_ref = ops.quick_gelu_fwd(f1_ref)
+        f1, a = ops.gemm_gelu_fwd(h2, w1, b1)
+        assert torch.equal(f1, f1_ref) and torch.equal(a, a_ref)
+        z = h2.float() @ w1.float().t() + b1.float()
+        assert relerr(a, z * torch.sigmoid(1.702 * z)) < 4 * EPS16[dtype]
+        dy, w2 = rnd(T, vd, dtype=dtype, seed=3, scale=0.5), rnd(vd, vff, dtype=dtype, seed=4, scale=0.3)
+        da = ops.gemm_nt(dy, w2, b_t=True)
+        df1_ref = ops.quick_gelu_bwd(f1_ref, da)
+        df1 = ops.gemm_gelu_bwd(dy, w2, f1_ref)
+        assert torch.equal(df1, df1_ref)
+    finally:
+        ops.gemm_force_kernel(0)
+    f1b, ab = ops.gemm_gelu_fwd(h2, w1, b1)  # default dispatch
+    assert relerr(f1b, f1_ref.float()) < 2 * EPS16[dtype] and relerr(ab, a_ref.float()) < 3 * EPS16[dtype]
+    assert relerr(ops.gemm_gelu_bwd(dy, w2, f1_ref), df1_ref.float()) < 3 * EPS16[dtype]

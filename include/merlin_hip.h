@@ -207,6 +207,13 @@ int mh_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int r
  * Removes every 16-bit rounding of HF's residual adds (LlamaDecoderLayer: `hidden_states = residual + hidden_states`) from the
  * forward: BASELINE's "logits within 1e-3 rel fp16" at depth is limited by exactly those (profiles/r01_full_depth_rounding_attribution.txt). */
 int mh_norm_fwd_f32in(const float* x, const void* w, const void* b, void* y, void* x16, int rows, int d, float eps, int dt, void* stream);
+/* fp32 tensors at the START of the fp32 residual streams (engine.fp32_residual): the patch projection (mh_gemm with MH_EPI_OUT_F32), class / position
+ * embeddings added in fp32 (mh_vit_assemble_f32), pre_layrnorm from fp32 to fp32 (mh_layernorm_f32_to_f32; x16 = 16-bit copy of its input for the
+ * backward), the projector's fp32 output spliced with widened embedding rows (mh_embed_splice_fwd_f32) - HF CLIPVisionEmbeddings / pre_layrnorm
+ * (clip_encoder.py:79) and base_mmgpt.py:99-160 without a 16-bit rounding before the first residual add. */
+int mh_vit_assemble_f32(const float* patch, const void* cls, const void* pos, float* x, int N, int G2, int d, int dt, void* stream);
+int mh_layernorm_f32_to_f32(const float* x, const void* w, const void* b, float* y, void* x16, int rows, int d, float eps, int dt, void* stream);
+int mh_embed_splice_fwd_f32(const int64_t* ids, const int32_t* src, const void* embed, const float* feats, float* out, int T, int d, int dt, void* stream);
 int mh_layernorm_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw_partial, float* db_partial, int rows, int d, float eps, int dt, int accumulate_dx, void* stream);
 int mh_norm_bwd_partials(int rows);
 /* out[d] (dt) (+)= sum_r partial[r, d]  (finishes dw/db; also bias grads from mh_colsum) */

@@ -193,6 +193,32 @@ __global__ __launch_bounds__(256) void vit_assemble_k(const uint16_t* __restrict
   }
 }
 
+// fp32 form (engine.fp32_residual: the tower's residual stream starts from fp32 values): patch rows are the fp32 output of the patch
+// projection, x = fp32 [N, G2 + 1, d]
+template <int DT>
+__global__ __launch_bounds__(256) void vit_assemble_f32_k(const float* __restrict__ patch, const uint16_t* __restrict__ cls,
+                                                          const uint16_t* __restrict__ pos, float* __restrict__ x, int N, int G2, int d) {
+  const int vpr = d >> 3;
+  const int64_t total = (int64_t)N * (G2 + 1) * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int v = (int)(i % vpr);
+    const int64_t row = i / vpr;
+    const int tkn = (int)(row % (G2 + 1));
+    float a[8], b[8];
+    if (tkn == 0) {
+      unpack8<DT>(((const uint4*)cls)[v], a);
+    } else {
+      const float4 p0 = ((const float4*)(patch + row * d))[2 * v], p1 = ((const float4*)(patch + row * d))[2 * v + 1];
+      a[0] = p0.x; a[1] = p0.y; a[2] = p0.z; a[3] = p0.w; a[4] = p1.x; a[5] = p1.y; a[6] = p1.z; a[7] = p1.w;
+    }
+    unpack8<DT>(((const uint4*)(pos + (int64_t)tkn * d))[v], b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += b[k];
+    ((float4*)(x + row * d))[2 * v] = make_float4(a[0], a[1], a[2], a[3]);
+    ((float4*)(x + row * d))[2 * v + 1] = make_float4(a[4], a[5], a[6], a[7]);
+  }
+}
+
 // dst[r, c] (=|+=) src[r, c] for a [rows, cols] block of two row-major 16-bit matrices with their own row strides (pad /
 // un-pad of the patch-embedding weight and its gradient: widths that are not a multiple of 8 elements)
 template <int DT>
@@ -342,6 +368,11 @@ extern "C" int mh_im2col_patches(const void* pixels, int pix_dt, void* cols, int
 extern "C" int mh_vit_assemble(const void* patch, const void* cls, const void* pos, void* x, int N, int G2, int d, int dt, void* stream) {
   if (!patch || !cls || !pos || !x || N <= 0 || (d & 7)) return MH_ERR_ARG;
   DISPATCH16(dt, vit_assemble_k, grid_for((int64_t)N * (G2 + 1) * (d >> 3)), (const uint16_t*)patch, (const uint16_t*)cls, (const uint16_t*)pos, (uint16_t*)x, N, G2, d);
+  MH_LAUNCH_CHECK();
+}
+extern "C" int mh_vit_assemble_f32(const float* patch, const void* cls, const void* pos, float* x, int N, int G2, int d, int dt, void* stream) {
+  if (!patch || !cls || !pos || !x || N <= 0 || (d & 7)) return MH_ERR_ARG;
+  DISPATCH16(dt, vit_assemble_f32_k, grid_for((int64_t)N * (G2 + 1) * (d >> 3)), patch, (const uint16_t*)cls, (const uint16_t*)pos, x, N, G2, d);
   MH_LAUNCH_CHECK();
 }
 extern "C" int mh_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int accumulate, int dt, void* stream) {

@@ -178,6 +178,31 @@ __global__ __launch_bounds__(256) void embed_splice_fwd_k(const int64_t* __restr
   }
 }
 
+// fp32 form (engine.fp32_residual: the decoder's residual stream starts from fp32 values): feats = the projector's fp32 output, embedding rows widened
+template <int DT>
+__global__ __launch_bounds__(256) void embed_splice_fwd_f32_k(const int64_t* __restrict__ ids, const int32_t* __restrict__ src,
+                                                              const uint16_t* __restrict__ embed, const float* __restrict__ feats,
+                                                              float* __restrict__ out, int64_t T, int d) {
+  const int vpr = d >> 3;
+  const int64_t total = T * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / vpr;
+    const int v = (int)(i - t * vpr);
+    const int s = src ? src[t] : -1;
+    float4 lo, hi;
+    if (s >= 0) {
+      const float4* f4 = (const float4*)(feats + (int64_t)s * d);
+      lo = f4[2 * v]; hi = f4[2 * v + 1];
+    } else {
+      float f[8];
+      unpack8<DT>(((const uint4*)(embed + ids[t] * (int64_t)d))[v], f);
+      lo = make_float4(f[0], f[1], f[2], f[3]); hi = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    ((float4*)(out + t * d))[2 * v] = lo;
+    ((float4*)(out + t * d))[2 * v + 1] = hi;
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void embed_splice_bwd_k(const int64_t* __restrict__ ids, const int32_t* __restrict__ src,
                                                           const uint16_t* __restrict__ dout, uint16_t* __restrict__ dfeats,
@@ -366,6 +391,19 @@ extern "C" int mh_embed_splice_fwd(const int64_t* ids, const int32_t* src, const
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   hipLaunchKernelGGL(embed_splice_fwd_k<MH_BF16>, dim3(grid_for((int64_t)T * (d >> 3))), dim3(256), 0, as_stream(stream), ids, src,
                      (const uint16_t*)embed, (const uint16_t*)feats, (uint16_t*)out, (int64_t)T, d);
+  MH_LAUNCH_CHECK();
+}
+
+extern "C" int mh_embed_splice_fwd_f32(const int64_t* ids, const int32_t* src, const void* embed, const float* feats, float* out, int T, int d, int dt,
+                                       void* stream) {
+  if (!ids || !embed || !out || T <= 0 || (d & 7) || (src && !feats)) return MH_ERR_ARG;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(embed_splice_fwd_f32_k<MH_BF16>, dim3(grid_for((int64_t)T * (d >> 3))), dim3(256), 0, as_stream(stream), ids, src,
+                       (const uint16_t*)embed, feats, out, (int64_t)T, d);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(embed_splice_fwd_f32_k<MH_F16>, dim3(grid_for((int64_t)T * (d >> 3))), dim3(256), 0, as_stream(stream), ids, src,
+                       (const uint16_t*)embed, feats, out, (int64_t)T, d);
+  else return MH_ERR_DTYPE;
   MH_LAUNCH_CHECK();
 }
 

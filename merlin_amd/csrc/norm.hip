@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restric
 // the forward path are the GEMM operands.  This kernel is the stream's reader: y = norm(x) in 16 bits for the next GEMM, and
 // (x16 != NULL) the 16-bit copy of x that the backward keeps as the layer input.  Same arithmetic and summation order as
 // rmsnorm_fwd_k / layernorm_fwd_k; LN = true: LayerNorm (b != NULL).
-template <int DT, bool LN>
+// Y32 = true: y is fp32 (the CLIP tower's pre_layrnorm writes the INITIAL value of the fp32 stream).
+template <int DT, bool LN, bool Y32 = false>
 __global__ __launch_bounds__(256) void norm_fwd_f32in_k(const float* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
                                                         uint16_t* __restrict__ y, uint16_t* __restrict__ x16, int rows, int d, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,7 +235,13 @@ __global__ __launch_bounds__(256) void norm_fwd_f32in_k(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
     }
-    yr[c] = pack8<DT>(f);
+    if constexpr (Y32) {
+      float4* y4 = (float4*)((float*)y + (int64_t)row * d);
+      y4[2 * c] = make_float4(f[0], f[1], f[2], f[3]);
+      y4[2 * c + 1] = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+      yr[c] = pack8<DT>(f);
+    }
   }
 }
 
@@ -567,6 +574,22 @@ extern "C" int mh_norm_fwd_f32in(const float* x, const void* w, const void* b, v
   if (dt == MH_BF16) { if (b) NF32_GO(MH_BF16, true); else NF32_GO(MH_BF16, false); }
   else { if (b) NF32_GO(MH_F16, true); else NF32_GO(MH_F16, false); }
 #undef NF32_GO
+  MH_LAUNCH_CHECK();
+}
+
+// LayerNorm of an fp32 tensor INTO an fp32 tensor (+ the 16-bit copy of the input the backward keeps): the CLIP tower's pre_layrnorm when its
+// residual stream is fp32 (engine.fp32_residual) - the stream then starts from unrounded values.
+extern "C" int mh_layernorm_f32_to_f32(const float* x, const void* w, const void* b, float* y, void* x16, int rows, int d, float eps, int dt, void* stream) {
+  if (!x || !w || !b || !y || rows <= 0 || d <= 0 || (d & 7)) return MH_ERR_ARG;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(b) || (x16 && !aligned16(x16))) return MH_ERR_ARG;
+  const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL((norm_fwd_f32in_k<MH_BF16, true, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, (const uint16_t*)w, (const uint16_t*)b,
+                       (uint16_t*)y, (uint16_t*)x16, rows, d, eps);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL((norm_fwd_f32in_k<MH_F16, true, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, (const uint16_t*)w, (const uint16_t*)b,
+                       (uint16_t*)y, (uint16_t*)x16, rows, d, eps);
+  else return MH_ERR_DTYPE;
   MH_LAUNCH_CHECK();
 }
 

@@ -424,23 +424,30 @@ class HipEngine:
             return O.copy2d(A.view(VT + "embeddings.patch_embedding.weight", shape=(vd, K)), wp)
 
         wpad = self._derive("patch_wpad", _pad_patch_weight)
-        patch = O.gemm_nt(cols, wpad)
-        x0 = O.vit_assemble(patch, A.view(VT + "embeddings.class_embedding"), A.view(VT + "embeddings.position_embedding.weight", shape=(S, vd)), N, G2)
-        x = O.layernorm_fwd(x0, A.view(VT + "pre_layrnorm.weight"), A.view(VT + "pre_layrnorm.bias"), vc.layer_norm_eps)
         L = tower.layers_used
         train_tower = ctx is not None and ctx["train_tower"]
         xs, saves = [], []
         r32 = self.fp32_residual and not (ctx is not None and ctx.get("fp8"))
+        cls_w, pos_w = A.view(VT + "embeddings.class_embedding"), A.view(VT + "embeddings.position_embedding.weight", shape=(S, vd))
         if r32:
-            x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
+            # the fp32 stream STARTS from fp32 values (round 4): patch projection stored in fp32, class / position embeddings added in fp32,
+            # pre_layrnorm fp32 -> fp32; x0 = the 16-bit copy of its input the backward keeps.  (16-bit tensors at the start of the
+            # stream were a sixth of the full-depth logits error: profiles/r04_parity_floor.txt)
+            x0_32 = O.vit_assemble_f32(O.gemm_nt(cols, wpad, out_f32=True), cls_w, pos_w, N, G2)
+            x32, x0 = O.layernorm_f32_to_f32(x0_32, A.view(VT + "pre_layrnorm.weight"), A.view(VT + "pre_layrnorm.bias"), vc.layer_norm_eps,
+                                             want_x16=train_tower)
+            del x0_32
             for i in range(L):
                 x16, sv = self._vit_layer_fwd_r32(self.vit[i], x32, N, S, vc, keep=train_tower and self.save_activations, need_x16=train_tower)
                 if train_tower:
                     xs.append(x16)
                 saves.append(sv)
-            x = O.convert(x32, torch.empty_like(x))  # hidden_states[select_layer] as the projector's 16-bit GEMM operand
+            x = O.convert(x32, torch.empty(x32.shape, dtype=dt, device=dev))  # hidden_states[select_layer] as the projector's 16-bit GEMM operand
             del x32
             L = 0
+        else:
+            x0 = O.vit_assemble(O.gemm_nt(cols, wpad), cls_w, pos_w, N, G2)
+            x = O.layernorm_fwd(x0, A.view(VT + "pre_layrnorm.weight"), A.view(VT + "pre_layrnorm.bias"), vc.layer_norm_eps)
         fp8_tower = bool(ctx is not None and ctx.get("fp8_train") and self.fp8_tower and not r32 and vd % 128 == 0 and
                          vc.intermediate_size % 128 == 0)
         for i in range(L):
@@ -493,8 +500,9 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     # projector
     # ------------------------------------------------------------------------------------------
-    def projector(self, x, N, S, ctx=None):
-        """x [N*S, vd] (tower output incl. CLS rows) -> (feats2d, rows_per_img, row0, P)."""
+    def projector(self, x, N, S, ctx=None, out_f32=False):
+        """x [N*S, vd] (tower output incl. CLS rows) -> (feats2d, rows_per_img, row0, P).  out_f32: the features stay fp32 (they are spliced
+        straight into the decoder's fp32 residual stream)."""
         m = self.model
         proj = m.get_model().projector
         A = self.arena
@@ -502,7 +510,7 @@ class HipEngine:
         tower = m.get_model().vision_tower
         cls_keep = tower.select_feature == "cls_patch"
         if kind == "mlp":
-            feats = O.gemm_nt(x, A.view("model.projector.projector.weight"), bias=A.view("model.projector.projector.bias"))
+            feats = O.gemm_nt(x, A.view("model.projector.projector.weight"), bias=A.view("model.projector.projector.bias"), out_f32=out_f32)
             if ctx is not None:
                 ctx.update(proj_in=x)
             return feats, S, (0 if cls_keep else 1), (S if cls_keep else S - 1)
@@ -515,7 +523,7 @@ class HipEngine:
         stride = proj.conv_stride
         cols = O.conv3x3_cols(x, N, G, vd, stride, S, 1)
         w = A.view("model.projector.projector.weight", shape=(A.params["model.projector.projector.weight"].shape[0], vd * 9))
-        feats = O.gemm_nt(cols, w, bias=A.view("model.projector.projector.bias"))
+        feats = O.gemm_nt(cols, w, bias=A.view("model.projector.projector.bias"), out_f32=out_f32)
         Go = (G + 2 - 3) // stride + 1
         if ctx is not None:
             ctx.update(proj_in=cols, proj_conv=(N, G, vd, stride, S))
@@ -917,9 +925,10 @@ class HipEngine:
         feats = None
         use_images = tower is not None and images is not None and input_ids is not None and S != 1
         src = self.validate_and_index(input_ids, labels, am.contiguous() if attention_mask is not None else None, lens, images, use_images)
+        r32 = self.fp32_residual and not fp8  # (the fp8 paths run on 16-bit streams)
         if use_images:
             xt, N, Sv = self.tower(images, ctx)
-            feats, rpi, row0, P = self.projector(xt, N, Sv, ctx)
+            feats, rpi, row0, P = self.projector(xt, N, Sv, ctx, out_f32=r32 and inputs_embeds is None)
             assert (rpi, row0, P) == self._splice_geometry()
             ctx.update(src=src, n_feat_rows=feats.shape[0])
         general_mask = self._check_errors()  # the flags were produced before the tower was enqueued: no wait for compute
@@ -927,8 +936,13 @@ class HipEngine:
         if attention_mask is not None and (general_mask or self.force_unpad):
             unpad = O.mask_unpad_index(am.contiguous())
         ctx["unpad"] = unpad
+        x32 = None
         if inputs_embeds is not None:
             x = inputs_embeds.to(device=dev, dtype=dt).reshape(T, d).contiguous()
+        elif r32:  # the decoder's fp32 stream starts from the projector's fp32 output and the widened embedding rows
+            x = None
+            x32 = O.embed_splice_fwd_f32(input_ids.view(-1), src.view(-1) if src is not None else None,
+                                         A.view("model.embed_tokens.weight", shape=(cfg.vocab_size, d)), feats)
         else:
             x = O.embed_splice_fwd(input_ids.view(-1), src.view(-1) if src is not None else None,
                                    A.view("model.embed_tokens.weight", shape=(cfg.vocab_size, d)), feats)
@@ -943,9 +957,9 @@ class HipEngine:
             if want_grad:
                 raise RuntimeError("model.fp8_forward is the inference form (forward only); set model.fp8_training = True for the fp8 training step")
             F8 = getattr(self, "_fp8_fwd", None) or self.quantize_forward_weights()
-        r32 = self.fp32_residual and not fp8  # (the fp8 paths run on 16-bit streams)
         if r32:
-            x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
+            if x32 is None:
+                x32 = O.convert(x, torch.empty(x.shape, dtype=torch.float32, device=dev))
             for li, W in enumerate(self.llama):
                 x16, sv = self._llama_layer_fwd_r32(W, x32, B, S, lens, keep=want_grad and self.save_activations,
                                                     kv_out=(kv_cache.k[li], kv_cache.v[li]) if kv_cache is not None else None, unpad=unpad,

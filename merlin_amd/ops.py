@@ -956,6 +956,35 @@ def norm_fwd_f32in(x32, w, eps, b=None, want_x16=False):
     return y, x16
 
 
+def vit_assemble_f32(patch32, cls, pos, N, G2):
+    """fp32 form of vit_assemble: patch32 = the patch projection's fp32 output [N * (G2 + 1), d]; returns fp32 x."""
+    d = patch32.shape[1]
+    assert patch32.dtype == torch.float32 and patch32.is_contiguous()
+    x = torch.empty(N * (G2 + 1), d, dtype=torch.float32, device=patch32.device)
+    L.check(L.lib().mh_vit_assemble_f32(p(patch32), p(cls), p(pos), p(x), i32(N), i32(G2), i32(d), i32(dt_of(cls)), _stream()), "mh_vit_assemble_f32")
+    return x
+
+
+def layernorm_f32_to_f32(x32, w, b, eps, want_x16=False):
+    """(y32, x16 | None) = (LayerNorm(x32) in fp32, 16-bit copy of x32): the CLIP tower's pre_layrnorm at the start of the fp32 stream."""
+    rows, d = x32.shape
+    assert x32.dtype == torch.float32 and x32.is_contiguous()
+    y = torch.empty(rows, d, dtype=torch.float32, device=x32.device)
+    x16 = torch.empty(rows, d, dtype=w.dtype, device=x32.device) if want_x16 else None
+    L.check(L.lib().mh_layernorm_f32_to_f32(p(x32), p(w), p(b), p(y), p(x16), i32(rows), i32(d), f32(eps), i32(dt_of(w)), _stream()), "mh_layernorm_f32_to_f32")
+    return y, x16
+
+
+def embed_splice_fwd_f32(ids, src, embed, feats32):
+    """fp32 form of embed_splice_fwd: embedding rows widened, image rows taken from the projector's fp32 output."""
+    T = ids.numel()
+    d = embed.shape[1]
+    assert feats32 is None or (feats32.dtype == torch.float32 and feats32.is_contiguous())
+    out = torch.empty(T, d, dtype=torch.float32, device=embed.device)
+    L.check(L.lib().mh_embed_splice_fwd_f32(p(ids), p(src), p(embed), p(feats32), p(out), i32(T), i32(d), i32(dt_of(embed)), _stream()), "mh_embed_splice_fwd_f32")
+    return out
+
+
 def mask_unpad_index(mask):
     """bool/uint8 mask [B, S] -> (fwd int64 [B*S], inv int64 [B*S], count int32 [B]): the unpad / pad row tables of the key-padding
     attention branch (include/merlin_hip.h: mh_mask_unpad_index), consumed by gather_rows2d."""

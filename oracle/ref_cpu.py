@@ -42,8 +42,9 @@ IGNORE_INDEX = -100  # mmgpt/utils/constants.py:7
 # both attentions - and, with stream=True, the residual streams after every add as well.  Accumulation, norms, softmax, RoPE, SwiGLU
 # stay fp32.  The logits error of that run against the reference golden is the FLOOR of any single-pass 16-bit-operand implementation:
 # what the HIP path's own error is held against.  outputs=True additionally rounds the GEMM outputs the HIP path STORES in 16 bits
-# before an element-wise op consumes them (q | k before the rotation, gate | up before SwiGLU: the fused epilogues work on the rounded
-# values so that fused and unfused kernels agree bit for bit) - the storage-format model of the HIP path itself.
+# before an element-wise op consumes them (q | k before the rotation, gate | up before SwiGLU: the 8-wave kernel's staged epilogues work on
+# the rounded values so that fused and unfused kernels agree bit for bit; the 4-wave kernel's forms work on the fp32 accumulators) and, with
+# 16-bit streams, the 16-bit tensors at the start of the streams - an upper model of the HIP path's own storage format.
 _ROUND = None
 
 
@@ -73,6 +74,12 @@ def _qs(x):
 def _qo(x):
     """a GEMM output stored in 16 bits ahead of a fused element-wise op"""
     return x if (_ROUND is None or not _ROUND[2]) else x.to(_ROUND[0]).to(x.dtype)
+
+
+def _q0(x):
+    """a 16-bit tensor at the START of a residual stream (patch projection, assembled embeddings, pre-LN output, projector output): the HIP
+    path keeps these in 16 bits only when the stream itself is 16-bit (with fp32 streams they are fp32 since round 4)"""
+    return x if (_ROUND is None or not (_ROUND[1] and _ROUND[2])) else x.to(_ROUND[0]).to(x.dtype)
 
 
 def _linear(x, w, b=None):
@@ -178,12 +185,11 @@ def clip_tower_forward(P: dict, cfg: OracleConfig, pixels: torch.Tensor) -> torc
     N = pixels.shape[0]
     vd, nh = cfg.v_hidden_size, cfg.v_num_attention_heads
     hd = vd // nh
-    x = _qo(F.conv2d(_q(pixels), P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size))
+    x = _q0(F.conv2d(_q(pixels), P[VT + "embeddings.patch_embedding.weight"], stride=cfg.v_patch_size))
     x = x.flatten(2).transpose(1, 2)  # [N, grid^2, vd]
     cls = P[VT + "embeddings.class_embedding"].expand(N, 1, -1)
-    x = _qo(torch.cat([cls, x], dim=1) + P[VT + "embeddings.position_embedding.weight"][None])
-    # (the HIP path's tower starts from 16-bit tensors - patch projection, assembled embeddings, pre-LN output - whatever its stream holds later)
-    x = _qo(_qs(F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps)))
+    x = _q0(torch.cat([cls, x], dim=1) + P[VT + "embeddings.position_embedding.weight"][None])
+    x = _qs(F.layer_norm(x, (vd,), P[VT + "pre_layrnorm.weight"], P[VT + "pre_layrnorm.bias"], cfg.v_layer_norm_eps))
     for i in range(cfg.v_layers_used):
         p = VT + f"encoder.layers.{i}."
         r = x
@@ -310,7 +316,7 @@ def forward(P: dict, cfg: OracleConfig, input_ids, attention_mask=None, labels=N
     """MMGPTLlamaForCausalLM.forward (llama_mmgpt.py:53-112).  Returns (loss|None, logits)."""
     if images is not None and input_ids.shape[1] != 1:
         feats = encode_images(P, cfg, images)
-        x = _qo(_qs(splice_image_features(P, cfg, input_ids, feats)))  # (projector output / embedding rows: 16-bit before the decoder's stream)
+        x = _qs(splice_image_features(P, cfg, input_ids, feats))
     else:
         x = F.embedding(input_ids, P["model.embed_tokens.weight"])
     h = llama_forward(P, cfg, x, attention_mask)

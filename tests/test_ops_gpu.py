@@ -1115,3 +1115,35 @@ def test_gemm_with_fused_quick_gelu_is_bit_identical_to_unfused(ops, dtype, T, v
     f1b, ab = ops.gemm_gelu_fwd(h2, w1, b1)  # default dispatch
     assert relerr(f1b, f1_ref.float()) < 2 * EPS16[dtype] and relerr(ab, a_ref.float()) < 3 * EPS16[dtype]
     assert relerr(ops.gemm_gelu_bwd(dy, w2, f1_ref), df1_ref.float()) < 3 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fp32_stream_start_kernels(ops, dtype):
+    """The fp32 residual streams start from fp32 tensors (round 4): class / position embeddings added to the fp32 patch projection, pre_layrnorm
+    fp32 -> fp32 (+ the 16-bit copy of its input for the backward), the projector's fp32 output spliced with widened embedding rows."""
+    N, G2, d = 3, 16, 128
+    S = G2 + 1
+    patch32 = torch.randn(N * S, d, device=dev())
+    cls, pos = rnd(d, dtype=dtype, seed=1), rnd(S, d, dtype=dtype, seed=2)
+    x = ops.vit_assemble_f32(patch32, cls, pos, N, G2)
+    ref = torch.cat([cls.float().expand(N, 1, d), patch32.view(N, S, d)[:, 1:]], 1) + pos.float()[None]
+    assert x.dtype == torch.float32 and torch.equal(x.view(N, S, d), ref)
+    w, b = rnd(d, dtype=dtype, seed=3), rnd(d, dtype=dtype, seed=4)
+    y, x16 = ops.layernorm_f32_to_f32(x, w, b, 1e-5, want_x16=True)
+    want = torch.nn.functional.layer_norm(x, (d,), w.float(), b.float(), 1e-5)
+    assert y.dtype == torch.float32 and relerr(y, want) < 1e-5 and torch.equal(x16, x.to(dtype))
+    y2, none = ops.layernorm_f32_to_f32(x, w, b, 1e-5)
+    assert none is None and torch.equal(y2, y)
+    # splice
+    V, P = 50, 4
+    ids = torch.randint(0, V, (2, 12), device=dev())
+    src = torch.full((2, 12), -1, dtype=torch.int32, device=dev())
+    src[0, 2:6] = torch.arange(0, 4, dtype=torch.int32)
+    src[1, 5:9] = torch.arange(4, 8, dtype=torch.int32)
+    emb, feats32 = rnd(V, d, dtype=dtype, seed=5), torch.randn(8, d, device=dev())
+    out = ops.embed_splice_fwd_f32(ids.view(-1), src.view(-1), emb, feats32)
+    want = emb.float()[ids.view(-1)].clone()
+    sel = src.view(-1) >= 0
+    want[sel] = feats32[src.view(-1)[sel].long()]
+    assert out.dtype == torch.float32 and torch.equal(out, want)
+    assert torch.equal(ops.embed_splice_fwd_f32(ids.view(-1), None, emb, None), emb.float()[ids.view(-1)])

@@ -19,6 +19,8 @@ cd $R
 python bench.py --steps 4 --warmup 2 --force-dp --no-cpu-baseline --no-extras > gpurun_out/bench_r04_force_dp_$TAG.json 2> gpurun_out/bench_r04_force_dp_$TAG.err
 MH_GEMM_PERSISTENT=0 python bench.py --steps 4 --warmup 2 --force-dp --no-cpu-baseline --no-extras > gpurun_out/bench_r04_force_dp_nonpersistent_$TAG.json 2>> gpurun_out/bench_r04_force_dp_$TAG.err
 python bench.py --config cfg5 --steps 6 --warmup 3 --no-cpu-baseline > gpurun_out/bench_r04_cfg5_$TAG.json 2> /dev/null
+python tools/bench_gemm_shapes.py > gpurun_out/r04_gemm_shapes_$TAG.txt 2>&1
+(cd tools && python yardstick.py > ../gpurun_out/r04_yardstick_$TAG.txt 2>&1)
 if [ "${SKIP_PMC:-0}" != "1" ]; then cp gpurun_out/r04_gemm_traffic.json profiles/r04_gemm_traffic.json; fi
 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_r04_default_$TAG.json 2> /dev/null
 head -30 gpurun_out/r04_step_cfg3_kernel_stats_$TAG.txt; head -c 1800 gpurun_out/r04_gemm_traffic.json; python -c "

@@ -144,7 +144,9 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     # them with split-K.  tests/test_parity_floor_gpu.py holds the same errors against the measured 16-bit-operand floor.
     tl, trms, tloss = (5e-3, 1.25e-3, 2e-3) if dtype == torch.float16 else (5e-2, 1.0e-2, 1e-2)
     if stream == "fp32":
-        tl, trms = (2.6e-3, 6.0e-4) if dtype == torch.float16 else (2.2e-2, 4.8e-3)
+        # (round 4: the streams start from fp32 tensors and RoPE / SwiGLU run on the fp32 accumulators - measured 2.10e-3 / 4.03e-4 and 1.46e-2 / 3.22e-3,
+        #  i.e. the 16-bit-operand floor itself; the rms bounds follow with 15 % margin, the single-element maxima keep their round-3 bounds)
+        tl, trms = (2.6e-3, 4.7e-4) if dtype == torch.float16 else (2.2e-2, 3.8e-3)
     dlt = got - g["logits_slice"]
     err = np.abs(dlt).max() / float(g["logits_absmax"])
     rms = float(np.sqrt((dlt.astype(np.float64) ** 2).mean())) / float(g["logits_absmax"])

@@ -8,9 +8,9 @@ Accumulation, norms, softmax, RoPE and SwiGLU stay fp32 there.  Its error agains
 16-bit-operand implementation pays ("operand-only floor").  The HIP path additionally keeps its GEMM outputs - q | k before the rotation,
 gate | up before SwiGLU - in 16 bits (the fused epilogues work on the rounded values, bit-identical to the unfused kernels): the same
 oracle with those roundings added (rounding(outputs=True)) is the "storage-model floor" = what the path's DATA FORMAT costs whatever the
-kernels do.  This file asserts that the HIP path stays within a stated factor of both, for the rms, the 99.9th percentile and the
-single-element maximum, on the medium model and at full 7B depth, in the engine's default configuration (fp32 residual streams) and with
-16-bit streams.
+kernels do.  This file asserts, for the rms, the 99.9th percentile and the single-element maximum, on the medium model and at full 7B depth, that the
+engine's DEFAULT configuration (fp32 residual streams that start from fp32 tensors; RoPE / SwiGLU on the fp32 accumulators of the 4-wave GEMM) stays
+within a stated factor of the OPERAND-ONLY floor, and the 16-bit-stream configuration within the same factor of its storage-model floor.
 The 1e-3 tolerance itself is met at every size by the fp32-store parity mode (tests/test_parity_mode_gpu.py)."""
 import os
 
@@ -22,10 +22,11 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-# factors the HIP statistics are held to (measured: profiles/r04_parity_floor.txt): against the STORAGE-MODEL floor (operands + the GEMM
-# outputs the HIP path keeps in 16 bits ahead of RoPE / SwiGLU: what the path's own data format costs, kernels aside) rms 1.10, p99.9
-# 1.15, single-element maximum 1.35 (one element of 40 k: scatters with summation order); against the operand-only floor rms 1.45
-F_RMS, F_P999, F_MAX, F_RMS_OPERANDS = 1.10, 1.15, 1.35, 1.45
+# factors the HIP statistics are held to (measured: profiles/r04_parity_floor.txt).  Default configuration (fp32 residual streams, which since
+# round 4 also START from fp32 tensors, RoPE / SwiGLU on the fp32 accumulators): against the OPERAND-ONLY floor itself - rms 1.10 (measured 1.00 - 1.02),
+# p99.9 1.15 (0.95 - 1.05), single-element maximum 1.35 (one element of 40 k: 0.82 - 1.15).  16-bit streams: the same factors against the storage-model floor
+# (operands + the 16-bit streams and the 16-bit tensors at their start), rms 1.25 against the operand-only floor (measured 1.01 - 1.10).
+F_RMS, F_P999, F_MAX, F_RMS_OPERANDS_16 = 1.10, 1.15, 1.35, 1.25
 
 
 def _stats(got, g):
@@ -71,7 +72,11 @@ def test_hip_logits_error_within_a_factor_of_the_16bit_operand_floor(name, dtype
               f"HIP max {hm:.3e} p99.9 {hp:.3e} rms {hr:.3e} | storage-model floor max {fm:.3e} p99.9 {fp_:.3e} rms {fr:.3e} "
               f"(ratios {hm / fm:.2f} {hp / fp_:.2f} {hr / fr:.2f}) | operand-only floor max {om:.3e} p99.9 {op_:.3e} rms {or_:.3e} "
               f"(ratios {hm / om:.2f} {hp / op_:.2f} {hr / or_:.2f})")
-        if hr > F_RMS * fr or hp > F_P999 * fp_ or hm > F_MAX * fm or hr > F_RMS_OPERANDS * or_:
+        if stream32:  # the default: held to the operand-only floor itself
+            fail = hr > F_RMS * or_ or hp > F_P999 * op_ or hm > F_MAX * om
+        else:
+            fail = hr > F_RMS * fr or hp > F_P999 * fp_ or hm > F_MAX * fm or hr > F_RMS_OPERANDS_16 * or_
+        if fail:
             bad.append((stream32, hip[stream32], floor[stream32], floor_op[stream32]))
     assert not bad, bad
     # and the fp32 stream is never worse than the 16-bit one (rms)

@@ -63,3 +63,19 @@ def test_host_side_launch_plans():
         assert 1 < s <= 16 and (s - 1) * ((nk + s - 1) // s) < nk, (M, N, K, s)  # no empty split
     assert int(lib.mh_attn_decode_splits(C.c_int(1), C.c_int(32), C.c_int(4096))) == 32
     assert int(lib.mh_attn_decode_splits(C.c_int(8), C.c_int(32), C.c_int(4096))) == 4
+
+
+def test_grouped_wgrad_host_plan_and_struct_layout():
+    """Host side of mh_wgrad_grouped: the launch-plan predicate (a CLIP-L layer's four weight gradients over 27 696 tokens are grouped, the tiny
+    test models' are not, odd widths never) and the ctypes mirror of `MhWgradProblem` (include/merlin_hip.h) - 3 pointers + 3 strides + 4 ints."""
+    import ctypes as C
+
+    from merlin_amd import ops as O
+
+    vd, vff = 1024, 4096
+    assert O.wgrad_group_pays(48 * 577, [(vd, vff), (vff, vd), (vd, vd), (3 * vd, vd)])
+    assert not O.wgrad_group_pays(3 * 17, [(128, 256), (256, 128), (128, 128), (384, 128)])       # tiny fixture: a few tiles, a few tokens
+    assert not O.wgrad_group_pays(48 * 577, [(vd, vff), (vff, vd), (vd, vd), (3 * vd, vd + 4)])  # a width the kernel cannot take
+    assert not O.wgrad_group_pays(48 * 577, [(vd, vff)] * 9)                                      # more problems than one launch holds
+    assert C.sizeof(O._WgradProblem) == 64
+    assert [f[0] for f in O._WgradProblem._fields_] == ["dy", "lddy", "x", "ldx", "out", "ldo", "M", "N", "accumulate", "reserved"]

@@ -213,7 +213,7 @@ struct RopeSpec {
 // gate|up + SwiGLU: rotated / gated on the fp32 accumulators), bit 5 = the SwiGLU-backward dgrad, bit 6 = fp32 outputs of NT products
 // (lm_head logits, the fp32 residual streams' accumulating projections), bit 7 = the fused forward forms at any size (see the call site).
 // Measured per bit in the step: profiles/r04_gemm_w4_policy.txt.
-int g_w4_mask = 3 | 8 | 16 | 64 | 128;  // (bit 5 off: the SwiGLU-backward dgrad measures -0.9 % there and gains nothing numerically)
+int g_w4_mask = 3 | 8 | 16 | 32 | 64 | 128;  // (everything: with the prefetching epilogues every form measures at or above the 8-wave kernel)
 extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
 static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi, const RopeSpec& fx) {
   (void)M; (void)N;
@@ -223,9 +223,9 @@ static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi, const Ro
   const int form = (a_ks && b_ks) ? 1 : (b_ks ? 2 : (a_ks ? 0 : 4));
   if (epi & MH_EPI_OUT_F32) {
     if (form == 1) return (g_w4_mask & 1) != 0;   // split-K partials of a weight gradient
-    // plain fp32 store (lm_head: +4.7 %); the accumulating store into an fp32 residual stream only behind a long contraction (down
-    // projection, K = 11008: +2.1 %; o projection, K = 4096: -4.5 %) - profiles/r04_w4_forms_ab.txt
-    return form == 4 && (g_w4_mask & 64) != 0 && (!(epi & MH_EPI_ACCUM) || K >= 8192);
+    // plain fp32 store (lm_head: +4.3 %) and the accumulating store into an fp32 residual stream (old values requested 16 tiles ahead:
+    // o projection +3.4 %, down projection +4.4 %) - profiles/r04_w4_forms_ab.txt
+    return form == 4 && (g_w4_mask & 64) != 0;
   }
   if (!(g_w4_mask & form)) return false;
   if (form == 4) return (epi & ~MH_EPI_ACCUM) == 0 || (epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL;

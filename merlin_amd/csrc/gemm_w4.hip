@@ -357,23 +357,44 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  if constexpr (EK == EK_F32 || EK == EK_F32ACC) {
+  if constexpr (EK == EK_F32) {
     // fp32 C straight from the accumulators (16 bytes per lane = 64 contiguous bytes per row and instruction)
     float* cb = (float*)g.C + (int64_t)ky * g.c_split;
     w4_for<64>([&](auto T_) {
       constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
       const int m = m0 + wm * 128 + i * 16 + (lane & 15);
       const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
-      if (m < g.M && n < g.N) {
-        float4* dst = (float4*)(cb + (int64_t)m * g.ldc + n);
-        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        if constexpr (EK == EK_F32ACC) {
-          const float4 o = *dst;
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        *dst = v;
-      }
+      if (m < g.M && n < g.N) *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       if constexpr (tt % 8 == 7) W4_FENCE();
+    });
+    return;
+  } else if constexpr (EK == EK_F32ACC) {
+    // fp32 C += accumulators (the fp32 residual streams).  The old values do not depend on anything the block computed: they are requested
+    // 16 accumulator tiles AHEAD of their use (two register sets of 16 float4 alternate), so a tile pays the memory latency once instead of
+    // once per group of stores (measured per-tile fixed cost of the naive read-modify-write: 32 us against 11 us for the plain fp32 store)
+    float* cb = (float*)g.C;
+    float4 old[2][16];
+    auto addr = [&](int tt) {  // clamped (always a valid address; the store below is guarded)
+      const int i = tt / 8, j = tt % 8;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
+      return (float4*)(cb + (int64_t)m * g.ldc + n);
+    };
+    w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[0][t] = *addr(t); });
+    W4_FENCE();
+    w4_for<4>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      if constexpr (c + 1 < 4) w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[(c + 1) & 1][t] = *addr((c + 1) * 16 + t); });
+      W4_FENCE();
+      w4_for<16>([&](auto T_) {
+        constexpr int t = decltype(T_)::value, tt = c * 16 + t, i = tt / 8, j = tt % 8;
+        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+        const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
+        const float4 o = old[c & 1][t];
+        if (m < g.M && n < g.N)
+          *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w);
+      });
+      W4_FENCE();
     });
     return;
   } else {
@@ -456,19 +477,36 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
     // (the v heads behind rope_cols take the same block with (cos, sin) = (1, 0): x * 1 - y * 0 is exact, and ONE store block avoids the
     // accumulator spills hipcc produces around a merge of two)
     const bool rot = n0 + wn * 128 < g.rope_cols;
-    w4_for<32>([&](auto T_) {
-      constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
+    // (cos, sin) of row group i + 1 are requested while group i is rotated and staged (two register sets of 8 float4): the table reads
+    // (L2-resident, but ~1 us away) are paid once per tile instead of once per row group
+    float4 tb[2][8];
+    auto fetch = [&](auto I_) {
+      constexpr int i = decltype(I_)::value;
       const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
-      const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + j * 16 + 4 * (lane >> 4)) * 2);
-      const float4 t01 = t4[0], t23 = t4[1];  // (c0, s0, c1, s1), (c2, s2, c3, s3)
-      const float cs[4] = {rot ? t01.x : 1.f, rot ? t01.z : 1.f, rot ? t23.x : 1.f, rot ? t23.z : 1.f};
-      const float sn[4] = {rot ? t01.y : 0.f, rot ? t01.w : 0.f, rot ? t23.y : 0.f, rot ? t23.w : 0.f};
-      float lo[4], hi[4];
+      const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + 4 * (lane >> 4)) * 2);
+      w4_for<4>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        tb[i & 1][2 * j] = t4[8 * j];          // channels j*16 + 4*(lane>>4) + {0, 1}: (c0, s0, c1, s1)
+        tb[i & 1][2 * j + 1] = t4[8 * j + 1];  // + {2, 3}
+      });
+    };
+    fetch(integral_constant<int, 0>{});
+    W4_FENCE();
+    w4_for<8>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      if constexpr (i + 1 < 8) fetch(integral_constant<int, i + 1>{});
+      w4_for<4>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        const float4 t01 = tb[i & 1][2 * j], t23 = tb[i & 1][2 * j + 1];
+        const float cs[4] = {rot ? t01.x : 1.f, rot ? t01.z : 1.f, rot ? t23.x : 1.f, rot ? t23.z : 1.f};
+        const float sn[4] = {rot ? t01.y : 0.f, rot ? t01.w : 0.f, rot ? t23.y : 0.f, rot ? t23.w : 0.f};
+        float lo[4], hi[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rope_rot(acc[i][j][e], acc[i][j + 4][e], cs[e], sn[e], lo[e], hi[e]);
-      stage8(lo, integral_constant<int, i * 16 * 272 + j * 32>{});
-      stage8(hi, integral_constant<int, i * 16 * 272 + (j + 4) * 32>{});
-      if constexpr (tt % 4 == 3) W4_FENCE();
+        for (int e = 0; e < 4; ++e) rope_rot(acc[i][j][e], acc[i][j + 4][e], cs[e], sn[e], lo[e], hi[e]);
+        stage8(lo, integral_constant<int, i * 16 * 272 + j * 32>{});
+        stage8(hi, integral_constant<int, i * 16 * 272 + (j + 4) * 32>{});
+      });
+      W4_FENCE();
     });
   } else if constexpr (EK == EK_SWIGLU_BWD) {
     fill(integral_constant<int, 0>{});  // dact, rounded to 16 bits as the unfused path stores it
@@ -482,30 +520,47 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   const int ncol = n0 + wn * 128 + (lane & 15) * 8;
   const bool n_ok = ncol < g.N;
   if constexpr (EK == EK_SWIGLU_BWD) {
-    // dgu[m, n] , dgu[m, ff + n] from gu[m, n], gu[m, ff + n] and the staged dact chunk: 16-byte rows pieces in and out
-    const uint16_t* gup = (const uint16_t*)g.sw_in + (int64_t)mrow * g.sw_ldi + ncol;
+    // dgu[m, n] , dgu[m, ff + n] from gu[m, n], gu[m, ff + n] and the staged dact chunk: 16-byte row pieces in and out.  The gu pieces of the
+    // NEXT 32-row part are requested while the current part is computed and stored (two register sets): their latency is paid once per
+    // tile, behind the LDS round trip of the first part, instead of once per part.
+    const int ncl = min(ncol, g.N - 8);  // (clamped: always a valid address; stores are guarded)
+    const uint16_t* gup = (const uint16_t*)g.sw_in + ncl;
     uint16_t* dgp = (uint16_t*)g.sw_out + (int64_t)mrow * g.sw_ldo + ncol;
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
+    uint4 gq[2][8], uq[2][8];
+    auto fetch = [&](auto P_) {
+      constexpr int part = decltype(P_)::value;
+      w4_for<8>([&](auto R_) {
+        constexpr int r = decltype(R_)::value;
+        const uint16_t* src = gup + (int64_t)min(mrow + part * 32 + r * 4, g.M - 1) * g.sw_ldi;
+        gq[part & 1][r] = *(const uint4*)src;
+        uq[part & 1][r] = *(const uint4*)(src + g.sw_ff);
+      });
+    };
+    fetch(integral_constant<int, 0>{});
+    W4_FENCE();
+    w4_for<4>([&](auto P_) {
+      constexpr int part = decltype(P_)::value;
       u32x4 rv[8];
       w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+      if constexpr (part + 1 < 4) fetch(integral_constant<int, part + 1>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       W4_FENCE();
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int row = part * 32 + r * 4;
-        if (n_ok && mrow + row < g.M) {
-          float d_[8], ga[8], ub[8], dg[8], du[8];
-          unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, d_);
-          unpack8<DT>(*(const uint4*)(gup + (int64_t)row * g.sw_ldi), ga);
-          unpack8<DT>(*(const uint4*)(gup + (int64_t)row * g.sw_ldi + g.sw_ff), ub);
+        float d_[8], ga[8], ub[8], dg[8], du[8];
+        unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, d_);
+        unpack8<DT>(gq[part & 1][r], ga);
+        unpack8<DT>(uq[part & 1][r], ub);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+        for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+        if (n_ok && mrow + row < g.M) {
           *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pack8<DT>(dg);
           *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pack8<DT>(du);
         }
       }
-    }
+      W4_FENCE();
+    });
     return;
   }
   uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;

@@ -211,9 +211,10 @@ struct RopeSpec {
 // Shapes that go to gemm_w4 by default (see the call site).  g_w4_mask: bit 0 = TN (wgrad, incl. its split-K form), bit 1 = NN (dgrad),
 // bit 2 = plain / residual NT, bit 3 = the fp8 NT products of the fp8 training step, bit 4 = the fused forward forms (q|k|v + RoPE,
 // gate|up + SwiGLU: rotated / gated on the fp32 accumulators), bit 5 = the SwiGLU-backward dgrad, bit 6 = fp32 outputs of NT products
-// (lm_head logits, the fp32 residual streams' accumulating projections), bit 7 = the fused forward forms at any size (see the call site).
+// (lm_head logits, the fp32 residual streams' accumulating projections), bit 7 = the fused forward forms at any size (see the call site),
+// bit 8 = the fused forms of the fp8 training step (RoPE, SwiGLU forward / backward, fp32 logits) on the 4-wave fp8 kernel.
 // Measured per bit in the step: profiles/r04_gemm_w4_policy.txt.
-int g_w4_mask = 3 | 8 | 16 | 32 | 64 | 128;  // (everything: with the prefetching epilogues every form measures at or above the 8-wave kernel)
+int g_w4_mask = 3 | 8 | 16 | 32 | 64 | 128 | 256;  // (everything: with the prefetching epilogues every form measures at or above the 8-wave kernel)
 extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
 static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi, const RopeSpec& fx) {
   (void)M; (void)N;
@@ -389,8 +390,9 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   g.tiles_n = fx.sw_mode == 1 ? (fx.sw_ff + 127) / 128 : (N + 255) / 256;
   // 4-wave form (gemm_w4.hip) for exponent-free operands with a plain / residual / accumulating epilogue when the tiles fill the
   // chip; mh_gemm_force_kernel(4) = wherever it can run, (256) = never; auto: mh_gemm_w4_policy bit 3
+  // (bit 3 of the policy mask: the plain / residual / accumulating products; bit 8: the fused forms - RoPE, SwiGLU forward / backward, the fp32 logits)
   if (g_force_kernel != 256 && w4_f8_can_run(g) &&
-      (g_force_kernel == 4 || (g_force_kernel == 0 && (g_w4_mask & 8) && (int64_t)g.tiles_m * g.tiles_n >= 192 && K >= 4096)))
+      (g_force_kernel == 4 || (g_force_kernel == 0 && (g_w4_mask & (w4_f8_is_fused(g) ? 256 : 8)) && (int64_t)g.tiles_m * g.tiles_n >= 192 && K >= 4096)))
     return launch_gemm_w4_f8(g, dt_out, as_stream(stream));
   return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
 }

@@ -239,6 +239,7 @@ bool w4_has_kernel(const GemmArgs& g, int a_kstrided, int b_kstrided);  // the (
 int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
 int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStream_t stream);  // n weight gradients (TN) over one K, one launch
 bool w4_f8_can_run(const GemmArgs& g);  // fp8 operands (no block exponents), see gemm_w4.hip
+bool w4_f8_is_fused(const GemmArgs& g);  // RoPE / SwiGLU / fp32-store kinds (own policy bit)
 int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream);
 int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA
 int launch_gemm_nt_w8(const GemmArgs& g, int dt, hipStream_t stream);      // gemm256w8.hip (8 waves, dense asm stream)

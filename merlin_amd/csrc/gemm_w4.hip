@@ -100,6 +100,279 @@ enum { EK_STD = 0,         // 16-bit C through the staged store: plain / residua
        EK_SWIGLU = 4,      // gate|up projection: a tile = 2 x (64 gate + 64 up) columns; C = gu, sw_out = act = silu(gate) * up
        EK_SWIGLU_BWD = 5 };  // dact = dY Wd -> sw_out = dgu from sw_in = gu (dact never stored)
 
+// The store phase of both 4-wave kernels (16-bit operands: F8 = false; fp8 operands: F8 = true, where an accumulator is first multiplied by
+// sc_m[row] * sc_n[column] - the per-row scales of the two quantised operands).  `acc` is the wave's 128 x 128 quadrant in accumulator registers.
+template <int DT, int EK, bool F8>
+__device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t (&acc)[8][8], int m0, int n0, int ky) {
+  using std::integral_constant;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  float smv[F8 ? 8 : 1];
+  float4 snv[F8 ? 8 : 1];
+  if constexpr (F8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) smv[i] = g.sc_m[min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // the B row (= output column) behind accumulator tile j; SwiGLU tiles hold 64 gate + 64 up columns per wave
+      const int n = EK == EK_SWIGLU ? ((j < 4 ? 0 : g.sw_ff) + n0 + wn * 64 + (j & 3) * 16 + 4 * (lane >> 4)) : (n0 + wn * 128 + j * 16 + 4 * (lane >> 4));
+      snv[j] = *(const float4*)(g.sc_n + min(n, g.N - 4));
+    }
+  }
+  auto val = [&](auto I_, auto J_, float (&v)[4]) {
+    constexpr int i = decltype(I_)::value, j = decltype(J_)::value;
+    v[0] = acc[i][j][0]; v[1] = acc[i][j][1]; v[2] = acc[i][j][2]; v[3] = acc[i][j][3];
+    if constexpr (F8) {
+      v[0] *= smv[i] * snv[j].x; v[1] *= smv[i] * snv[j].y; v[2] *= smv[i] * snv[j].z; v[3] *= smv[i] * snv[j].w;
+    }
+  };
+  if constexpr (EK == EK_F32) {
+    // fp32 C straight from the accumulators (16 bytes per lane = 64 contiguous bytes per row and instruction)
+    float* cb = (float*)g.C + (int64_t)ky * g.c_split;
+    w4_for<64>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
+      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
+      float v[4];
+      val(integral_constant<int, i>{}, integral_constant<int, j>{}, v);
+      if (m < g.M && n < g.N) *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if constexpr (tt % 8 == 7) W4_FENCE();
+    });
+    return;
+  } else if constexpr (EK == EK_F32ACC) {
+    // fp32 C += accumulators (the fp32 residual streams).  The old values do not depend on anything the block computed: they are requested
+    // 16 accumulator tiles AHEAD of their use (two register sets of 16 float4 alternate), so a tile pays the memory latency once instead of
+    // once per group of stores (measured per-tile fixed cost of the naive read-modify-write: 32 us against 11 us for the plain fp32 store)
+    float* cb = (float*)g.C;
+    float4 old[2][16];
+    auto addr = [&](int tt) {  // clamped (always a valid address; the store below is guarded)
+      const int i = tt / 8, j = tt % 8;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
+      return (float4*)(cb + (int64_t)m * g.ldc + n);
+    };
+    w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[0][t] = *addr(t); });
+    W4_FENCE();
+    w4_for<4>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      if constexpr (c + 1 < 4) w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[(c + 1) & 1][t] = *addr((c + 1) * 16 + t); });
+      W4_FENCE();
+      w4_for<16>([&](auto T_) {
+        constexpr int t = decltype(T_)::value, tt = c * 16 + t, i = tt / 8, j = tt % 8;
+        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+        const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
+        const float4 o = old[c & 1][t];
+        float v[4];
+        val(integral_constant<int, i>{}, integral_constant<int, j>{}, v);
+        if (m < g.M && n < g.N) *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);
+      });
+      W4_FENCE();
+    });
+    return;
+  } else {
+  // Staged epilogue (16-bit C): the accumulator layout gives a lane 4 consecutive n of one row, i.e. 32-byte pieces of 16 rows
+  // per store instruction.  Every wave instead packs its 128x128 quadrant into its own LDS slice ([128 rows][272 B]: 256 B of
+  // data + 16 B pad, conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 256
+  // contiguous bytes per row, 4 rows per instruction.  MH_EPI_ACCUM adds the old 16-bit values in fp32 on the way out.
+  __syncthreads();  // every wave is done with the operand tiles in LDS
+  char* stage = smem + wave * W4_CSTAGE;
+  const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
+  auto stage8 = [&](const float (&v)[4], auto OFF_) {
+    const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
+    const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(decltype(OFF_)::value) : "memory");
+  };
+  auto fill = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    w4_for<64>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
+      float v[4];
+      val(integral_constant<int, i>{}, integral_constant<int, j>{}, v);
+      epi_xform4<DT, EPI>(g, m, n, v);
+      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
+      if constexpr (tt % 8 == 7) W4_FENCE();  // (keeps hipcc from reading all 256 accumulators into VGPRs at once)
+    });
+  };
+  const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
+  const int mrow = m0 + wm * 128 + (lane >> 4);
+
+  if constexpr (EK == EK_SWIGLU) {
+    // quadrant = [64 gate | 64 up] columns n0 + 64 wn .. of ff: accumulator tiles j and j + 4 of a lane are (gate, up) of the same
+    // (token, channel).  Pass 1 stages and writes gu (both halves, rounded once); pass 2 computes act = silu(gate) * up from the fp32
+    // accumulators, stages its 64 columns in the same slice and writes them.
+    fill(integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int cq = lane & 15, gcol = n0 + wn * 64 + (cq & 7) * 8;  // channel (< ff) of this lane's 16-byte chunk
+    uint16_t* gp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + (cq < 8 ? 0 : g.sw_ff) + gcol;
+    const bool c_ok = gcol < g.sw_ff;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (c_ok && mrow + row < g.M) *(u32x4*)(gp + (int64_t)row * g.ldc) = rv[r];
+      }
+    }
+    w4_for<32>([&](auto T_) {
+      constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
+      float v[4], gt[4], up[4];
+      val(integral_constant<int, i>{}, integral_constant<int, j>{}, gt);
+      val(integral_constant<int, i>{}, integral_constant<int, j + 4>{}, up);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = swiglu_fwd1(gt[e], up[e]);
+      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
+      if constexpr (tt % 4 == 3) W4_FENCE();
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned st_r2 = lds_addr_of(stage) + (unsigned)(lane >> 3) * 272 + (unsigned)(lane & 7) * 16;
+    const int arow = m0 + wm * 128 + (lane >> 3), acol = n0 + wn * 64 + (lane & 7) * 8;
+    uint16_t* ap = (uint16_t*)g.sw_out + (int64_t)arow * g.sw_ldo + acol;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 8 * 272>(rv[r], st_r2 + (unsigned)part * 64 * 272); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 64 + r * 8;
+        if (acol < g.sw_ff && arow + row < g.M) *(u32x4*)(ap + (int64_t)row * g.sw_ldo) = rv[r];
+      }
+    }
+    return;
+  } else if constexpr (EK == EK_ROPE) {
+    // the wave's 128 columns are ONE head (n0 % 256 == 0, D = 128): channel c < 64 sits in accumulator tile j = c / 16, its rotary
+    // partner c + 64 in tile j + 4 of the same lane and row -> rotate-half RoPE on the fp32 accumulators, one rounding
+    // (the v heads behind rope_cols take the same block with (cos, sin) = (1, 0): x * 1 - y * 0 is exact, and ONE store block avoids the
+    // accumulator spills hipcc produces around a merge of two)
+    const bool rot = n0 + wn * 128 < g.rope_cols;
+    // (cos, sin) of row group i + 1 are requested while group i is rotated and staged (two register sets of 8 float4): the table reads
+    // (L2-resident, but ~1 us away) are paid once per tile instead of once per row group
+    float4 tb[2][8];
+    auto fetch = [&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + 4 * (lane >> 4)) * 2);
+      w4_for<4>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        tb[i & 1][2 * j] = t4[8 * j];          // channels j*16 + 4*(lane>>4) + {0, 1}: (c0, s0, c1, s1)
+        tb[i & 1][2 * j + 1] = t4[8 * j + 1];  // + {2, 3}
+      });
+    };
+    fetch(integral_constant<int, 0>{});
+    W4_FENCE();
+    w4_for<8>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      if constexpr (i + 1 < 8) fetch(integral_constant<int, i + 1>{});
+      w4_for<4>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        const float4 t01 = tb[i & 1][2 * j], t23 = tb[i & 1][2 * j + 1];
+        const float cs[4] = {rot ? t01.x : 1.f, rot ? t01.z : 1.f, rot ? t23.x : 1.f, rot ? t23.z : 1.f};
+        const float sn[4] = {rot ? t01.y : 0.f, rot ? t01.w : 0.f, rot ? t23.y : 0.f, rot ? t23.w : 0.f};
+        float lo[4], hi[4], xa[4], xb[4];
+        val(integral_constant<int, i>{}, integral_constant<int, j>{}, xa);
+        val(integral_constant<int, i>{}, integral_constant<int, j + 4>{}, xb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rope_rot(xa[e], xb[e], cs[e], sn[e], lo[e], hi[e]);
+        stage8(lo, integral_constant<int, i * 16 * 272 + j * 32>{});
+        stage8(hi, integral_constant<int, i * 16 * 272 + (j + 4) * 32>{});
+      });
+      W4_FENCE();
+    });
+  } else if constexpr (EK == EK_SWIGLU_BWD) {
+    fill(integral_constant<int, 0>{});  // dact, rounded to 16 bits as the unfused path stores it
+  } else {
+    // (two variants only: every further instantiation of this 64-tile block behind a switch makes hipcc spill more of the accumulators
+    // around the merge - the bias / quick-GELU epilogues belong to the CLIP tower's K = 1024 GEMMs, which stay on the 8-wave kernel anyway)
+    if ((g.epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL) fill(integral_constant<int, MH_EPI_RESIDUAL>{});
+    else fill(integral_constant<int, 0>{});
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int ncol = n0 + wn * 128 + (lane & 15) * 8;
+  const bool n_ok = ncol < g.N;
+  if constexpr (EK == EK_SWIGLU_BWD) {
+    // dgu[m, n] , dgu[m, ff + n] from gu[m, n], gu[m, ff + n] and the staged dact chunk: 16-byte row pieces in and out.  The gu pieces of the
+    // NEXT 32-row part are requested while the current part is computed and stored (two register sets): their latency is paid once per
+    // tile, behind the LDS round trip of the first part, instead of once per part.
+    const int ncl = min(ncol, g.N - 8);  // (clamped: always a valid address; stores are guarded)
+    const uint16_t* gup = (const uint16_t*)g.sw_in + ncl;
+    uint16_t* dgp = (uint16_t*)g.sw_out + (int64_t)mrow * g.sw_ldo + ncol;
+    uint4 gq[2][8], uq[2][8];
+    auto fetch = [&](auto P_) {
+      constexpr int part = decltype(P_)::value;
+      w4_for<8>([&](auto R_) {
+        constexpr int r = decltype(R_)::value;
+        const uint16_t* src = gup + (int64_t)min(mrow + part * 32 + r * 4, g.M - 1) * g.sw_ldi;
+        gq[part & 1][r] = *(const uint4*)src;
+        uq[part & 1][r] = *(const uint4*)(src + g.sw_ff);
+      });
+    };
+    fetch(integral_constant<int, 0>{});
+    W4_FENCE();
+    w4_for<4>([&](auto P_) {
+      constexpr int part = decltype(P_)::value;
+      u32x4 rv[8];
+      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+      if constexpr (part + 1 < 4) fetch(integral_constant<int, part + 1>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_FENCE();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        float d_[8], ga[8], ub[8], dg[8], du[8];
+        unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, d_);
+        unpack8<DT>(gq[part & 1][r], ga);
+        unpack8<DT>(uq[part & 1][r], ub);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
+        if (n_ok && mrow + row < g.M) {
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pack8<DT>(dg);
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pack8<DT>(du);
+        }
+      }
+      W4_FENCE();
+    });
+    return;
+  }
+  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
+  const bool accum = EK == EK_STD && (g.epi & MH_EPI_ACCUM) != 0;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    u32x4 rv[8];
+    w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+    if (accum) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (n_ok && mrow + row < g.M) {
+          const uint4 old = *(const uint4*)(cp + (int64_t)row * g.ldc);
+          float a[8], o[8];
+          unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, a);
+          unpack8<DT>(old, o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += o[e];
+          *(uint4*)(cp + (int64_t)row * g.ldc) = pack8<DT>(a);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = part * 32 + r * 4;
+        if (n_ok && mrow + row < g.M) *(u32x4*)(cp + (int64_t)row * g.ldc) = rv[r];
+      }
+    }
+  }
+  }
+}
+
 // max(0, span - off) in scalar arithmetic.  (Written as `off < span ? span - off : 0` or `span - min(off, span)` hipcc recognises an
 // unsigned saturating subtract, which exists only as a VALU instruction (v_sub_u32 clamp): the descriptor word would have to come back
 // through a VGPR -> SGPR copy the backend refuses.)
@@ -357,243 +630,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  if constexpr (EK == EK_F32) {
-    // fp32 C straight from the accumulators (16 bytes per lane = 64 contiguous bytes per row and instruction)
-    float* cb = (float*)g.C + (int64_t)ky * g.c_split;
-    w4_for<64>([&](auto T_) {
-      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
-      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-      const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
-      if (m < g.M && n < g.N) *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if constexpr (tt % 8 == 7) W4_FENCE();
-    });
-    return;
-  } else if constexpr (EK == EK_F32ACC) {
-    // fp32 C += accumulators (the fp32 residual streams).  The old values do not depend on anything the block computed: they are requested
-    // 16 accumulator tiles AHEAD of their use (two register sets of 16 float4 alternate), so a tile pays the memory latency once instead of
-    // once per group of stores (measured per-tile fixed cost of the naive read-modify-write: 32 us against 11 us for the plain fp32 store)
-    float* cb = (float*)g.C;
-    float4 old[2][16];
-    auto addr = [&](int tt) {  // clamped (always a valid address; the store below is guarded)
-      const int i = tt / 8, j = tt % 8;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
-      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
-      return (float4*)(cb + (int64_t)m * g.ldc + n);
-    };
-    w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[0][t] = *addr(t); });
-    W4_FENCE();
-    w4_for<4>([&](auto C_) {
-      constexpr int c = decltype(C_)::value;
-      if constexpr (c + 1 < 4) w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[(c + 1) & 1][t] = *addr((c + 1) * 16 + t); });
-      W4_FENCE();
-      w4_for<16>([&](auto T_) {
-        constexpr int t = decltype(T_)::value, tt = c * 16 + t, i = tt / 8, j = tt % 8;
-        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-        const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
-        const float4 o = old[c & 1][t];
-        if (m < g.M && n < g.N)
-          *(float4*)(cb + (int64_t)m * g.ldc + n) = make_float4(acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w);
-      });
-      W4_FENCE();
-    });
-    return;
-  } else {
-  // Staged epilogue (16-bit C): the accumulator layout gives a lane 4 consecutive n of one row, i.e. 32-byte pieces of 16 rows
-  // per store instruction.  Every wave instead packs its 128x128 quadrant into its own LDS slice ([128 rows][272 B]: 256 B of
-  // data + 16 B pad, conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 256
-  // contiguous bytes per row, 4 rows per instruction.  MH_EPI_ACCUM adds the old 16-bit values in fp32 on the way out.
-  __syncthreads();  // every wave is done with the operand tiles in LDS
-  char* stage = smem + wave * W4_CSTAGE;
-  const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
-  auto stage8 = [&](const float (&v)[4], auto OFF_) {
-    const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
-    const unsigned sw_ = st_w;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(decltype(OFF_)::value) : "memory");
-  };
-  auto fill = [&](auto EPI_) {
-    constexpr int EPI = decltype(EPI_)::value;
-    w4_for<64>([&](auto T_) {
-      constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
-      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epi_xform4<DT, EPI>(g, m, n, v);
-      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
-      if constexpr (tt % 8 == 7) W4_FENCE();  // (keeps hipcc from reading all 256 accumulators into VGPRs at once)
-    });
-  };
-  const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
-  const int mrow = m0 + wm * 128 + (lane >> 4);
-
-  if constexpr (EK == EK_SWIGLU) {
-    // quadrant = [64 gate | 64 up] columns n0 + 64 wn .. of ff: accumulator tiles j and j + 4 of a lane are (gate, up) of the same
-    // (token, channel).  Pass 1 stages and writes gu (both halves, rounded once); pass 2 computes act = silu(gate) * up from the fp32
-    // accumulators, stages its 64 columns in the same slice and writes them.
-    fill(integral_constant<int, 0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int cq = lane & 15, gcol = n0 + wn * 64 + (cq & 7) * 8;  // channel (< ff) of this lane's 16-byte chunk
-    uint16_t* gp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + (cq < 8 ? 0 : g.sw_ff) + gcol;
-    const bool c_ok = gcol < g.sw_ff;
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      u32x4 rv[8];
-      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_FENCE();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = part * 32 + r * 4;
-        if (c_ok && mrow + row < g.M) *(u32x4*)(gp + (int64_t)row * g.ldc) = rv[r];
-      }
-    }
-    w4_for<32>([&](auto T_) {
-      constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = swiglu_fwd1(acc[i][j][e], acc[i][j + 4][e]);
-      stage8(v, integral_constant<int, i * 16 * 272 + j * 32>{});
-      if constexpr (tt % 4 == 3) W4_FENCE();
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned st_r2 = lds_addr_of(stage) + (unsigned)(lane >> 3) * 272 + (unsigned)(lane & 7) * 16;
-    const int arow = m0 + wm * 128 + (lane >> 3), acol = n0 + wn * 64 + (lane & 7) * 8;
-    uint16_t* ap = (uint16_t*)g.sw_out + (int64_t)arow * g.sw_ldo + acol;
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      u32x4 rv[8];
-      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 8 * 272>(rv[r], st_r2 + (unsigned)part * 64 * 272); });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_FENCE();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = part * 64 + r * 8;
-        if (acol < g.sw_ff && arow + row < g.M) *(u32x4*)(ap + (int64_t)row * g.sw_ldo) = rv[r];
-      }
-    }
-    return;
-  } else if constexpr (EK == EK_ROPE) {
-    // the wave's 128 columns are ONE head (n0 % 256 == 0, D = 128): channel c < 64 sits in accumulator tile j = c / 16, its rotary
-    // partner c + 64 in tile j + 4 of the same lane and row -> rotate-half RoPE on the fp32 accumulators, one rounding
-    // (the v heads behind rope_cols take the same block with (cos, sin) = (1, 0): x * 1 - y * 0 is exact, and ONE store block avoids the
-    // accumulator spills hipcc produces around a merge of two)
-    const bool rot = n0 + wn * 128 < g.rope_cols;
-    // (cos, sin) of row group i + 1 are requested while group i is rotated and staged (two register sets of 8 float4): the table reads
-    // (L2-resident, but ~1 us away) are paid once per tile instead of once per row group
-    float4 tb[2][8];
-    auto fetch = [&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
-      const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + 4 * (lane >> 4)) * 2);
-      w4_for<4>([&](auto J_) {
-        constexpr int j = decltype(J_)::value;
-        tb[i & 1][2 * j] = t4[8 * j];          // channels j*16 + 4*(lane>>4) + {0, 1}: (c0, s0, c1, s1)
-        tb[i & 1][2 * j + 1] = t4[8 * j + 1];  // + {2, 3}
-      });
-    };
-    fetch(integral_constant<int, 0>{});
-    W4_FENCE();
-    w4_for<8>([&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      if constexpr (i + 1 < 8) fetch(integral_constant<int, i + 1>{});
-      w4_for<4>([&](auto J_) {
-        constexpr int j = decltype(J_)::value;
-        const float4 t01 = tb[i & 1][2 * j], t23 = tb[i & 1][2 * j + 1];
-        const float cs[4] = {rot ? t01.x : 1.f, rot ? t01.z : 1.f, rot ? t23.x : 1.f, rot ? t23.z : 1.f};
-        const float sn[4] = {rot ? t01.y : 0.f, rot ? t01.w : 0.f, rot ? t23.y : 0.f, rot ? t23.w : 0.f};
-        float lo[4], hi[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rope_rot(acc[i][j][e], acc[i][j + 4][e], cs[e], sn[e], lo[e], hi[e]);
-        stage8(lo, integral_constant<int, i * 16 * 272 + j * 32>{});
-        stage8(hi, integral_constant<int, i * 16 * 272 + (j + 4) * 32>{});
-      });
-      W4_FENCE();
-    });
-  } else if constexpr (EK == EK_SWIGLU_BWD) {
-    fill(integral_constant<int, 0>{});  // dact, rounded to 16 bits as the unfused path stores it
-  } else {
-    // (two variants only: every further instantiation of this 64-tile block behind a switch makes hipcc spill more of the accumulators
-    // around the merge - the bias / quick-GELU epilogues belong to the CLIP tower's K = 1024 GEMMs, which stay on the 8-wave kernel anyway)
-    if ((g.epi & ~MH_EPI_ACCUM) == MH_EPI_RESIDUAL) fill(integral_constant<int, MH_EPI_RESIDUAL>{});
-    else fill(integral_constant<int, 0>{});
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int ncol = n0 + wn * 128 + (lane & 15) * 8;
-  const bool n_ok = ncol < g.N;
-  if constexpr (EK == EK_SWIGLU_BWD) {
-    // dgu[m, n] , dgu[m, ff + n] from gu[m, n], gu[m, ff + n] and the staged dact chunk: 16-byte row pieces in and out.  The gu pieces of the
-    // NEXT 32-row part are requested while the current part is computed and stored (two register sets): their latency is paid once per
-    // tile, behind the LDS round trip of the first part, instead of once per part.
-    const int ncl = min(ncol, g.N - 8);  // (clamped: always a valid address; stores are guarded)
-    const uint16_t* gup = (const uint16_t*)g.sw_in + ncl;
-    uint16_t* dgp = (uint16_t*)g.sw_out + (int64_t)mrow * g.sw_ldo + ncol;
-    uint4 gq[2][8], uq[2][8];
-    auto fetch = [&](auto P_) {
-      constexpr int part = decltype(P_)::value;
-      w4_for<8>([&](auto R_) {
-        constexpr int r = decltype(R_)::value;
-        const uint16_t* src = gup + (int64_t)min(mrow + part * 32 + r * 4, g.M - 1) * g.sw_ldi;
-        gq[part & 1][r] = *(const uint4*)src;
-        uq[part & 1][r] = *(const uint4*)(src + g.sw_ff);
-      });
-    };
-    fetch(integral_constant<int, 0>{});
-    W4_FENCE();
-    w4_for<4>([&](auto P_) {
-      constexpr int part = decltype(P_)::value;
-      u32x4 rv[8];
-      w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
-      if constexpr (part + 1 < 4) fetch(integral_constant<int, part + 1>{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_FENCE();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = part * 32 + r * 4;
-        float d_[8], ga[8], ub[8], dg[8], du[8];
-        unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, d_);
-        unpack8<DT>(gq[part & 1][r], ga);
-        unpack8<DT>(uq[part & 1][r], ub);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
-        if (n_ok && mrow + row < g.M) {
-          *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pack8<DT>(dg);
-          *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pack8<DT>(du);
-        }
-      }
-      W4_FENCE();
-    });
-    return;
-  }
-  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
-  const bool accum = EK == EK_STD && (g.epi & MH_EPI_ACCUM) != 0;
-#pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    u32x4 rv[8];
-    w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    W4_FENCE();
-    if (accum) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = part * 32 + r * 4;
-        if (n_ok && mrow + row < g.M) {
-          const uint4 old = *(const uint4*)(cp + (int64_t)row * g.ldc);
-          float a[8], o[8];
-          unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, a);
-          unpack8<DT>(old, o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += o[e];
-          *(uint4*)(cp + (int64_t)row * g.ldc) = pack8<DT>(a);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = part * 32 + r * 4;
-        if (n_ok && mrow + row < g.M) *(u32x4*)(cp + (int64_t)row * g.ldc) = rv[r];
-      }
-    }
-  }
-  }
+  w4_store<DT, EK, false>(g, smem, acc, m0, n0, ky);
 }
 
 template <int DT, bool AKS, bool BKS, int EK>
@@ -659,7 +696,7 @@ __device__ __forceinline__ void mfma_f8_acc(f32x4_t& c, const i32x8& a, const i3
   asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(c) : "v"(a), "v"(b), "v"(scale));
 }
 
-template <int DT>
+template <int DT, int EK>
 __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -667,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
   tile_of_block(g, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * (EK == EK_SWIGLU ? 128 : 256);
   const int nk = g.K / BK;
   using std::integral_constant;
 
@@ -677,7 +714,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
     const int row = wave * 64 + j * 8 + (lane >> 3);
     const int c = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
     voffA[j] = (int)((int64_t)min(m0 + row, g.M - 1) * g.lda * 2 + c);
-    voffB[j] = (int)((int64_t)min(n0 + row, g.N - 1) * g.ldb * 2 + c);
+    int src = n0 + row;
+    if constexpr (EK == EK_SWIGLU) {  // part rows [64 q, 64 q + 64): q = 2 * (column half) + (0 gate | 1 up), as in the 16-bit kernel
+      const int q = row >> 6;
+      src = (q & 1) * g.sw_ff + n0 + (q >> 1) * 64 + (row & 63);
+    }
+    voffB[j] = (int)((int64_t)min(src, g.N - 1) * g.ldb * 2 + c);
   }
   auto make_rs = [](const void* p_) {
     const uint64_t a_ = (uint64_t)(uintptr_t)p_;
@@ -798,62 +840,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // epilogue: C[m, n] = sc_m[m] * sc_n[n] * acc, then the staged 16-bit store of gemm_w4 (plain / bias / gelu / residual / accumulate)
-  __syncthreads();
-  char* stage = smem + wave * W4_CSTAGE;
-  const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
-  float sm[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) sm[i] = g.sc_m[min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1)];
-  auto fill = [&](auto EPI_) {
-    constexpr int EPI = decltype(EPI_)::value;
-    w4_for<64>([&](auto T_) {
-      constexpr int tt = decltype(T_)::value, j = tt / 8, i = tt % 8;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
-      const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
-      const float4 sn = *(const float4*)(g.sc_n + n);
-      float v[4] = {acc[i][j][0] * (sm[i] * sn.x), acc[i][j][1] * (sm[i] * sn.y), acc[i][j][2] * (sm[i] * sn.z), acc[i][j][3] * (sm[i] * sn.w)};
-      epi_xform4<DT, EPI>(g, m, n, v);
-      const uint2 pk = make_uint2(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]));
-      const unsigned sw_ = st_w;
-      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sw_), "v"(pk), "n"(i * 16 * 272 + j * 32) : "memory");
-    });
-  };
-  switch (g.epi & ~MH_EPI_ACCUM) {
-    case 0: fill(integral_constant<int, 0>{}); break;
-    case MH_EPI_RESIDUAL: fill(integral_constant<int, MH_EPI_RESIDUAL>{}); break;
-    default: break;  // excluded by the host
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
-  const int mrow = m0 + wm * 128 + (lane >> 4);
-  const int ncol = n0 + wn * 128 + (lane & 15) * 8;
-  uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
-  const bool n_ok = ncol < g.N;
-  const bool accum = (g.epi & MH_EPI_ACCUM) != 0;
-#pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    u32x4 rv[8];
-    w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    W4_FENCE();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int row = part * 32 + r * 4;
-      if (!(n_ok && mrow + row < g.M)) continue;
-      if (accum) {
-        const uint4 old = *(const uint4*)(cp + (int64_t)row * g.ldc);
-        float a[8], o[8];
-        unpack8<DT>(uint4{rv[r][0], rv[r][1], rv[r][2], rv[r][3]}, a);
-        unpack8<DT>(old, o);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += o[e];
-        *(uint4*)(cp + (int64_t)row * g.ldc) = pack8<DT>(a);
-      } else {
-        *(u32x4*)(cp + (int64_t)row * g.ldc) = rv[r];
-      }
-    }
-  }
+  // store phase shared with the 16-bit kernel: C[m, n] = sc_m[m] * sc_n[n] * acc through the epilogue kind EK (plain / residual / accumulate, fp32 store,
+  // RoPE and SwiGLU on the scaled fp32 accumulators, SwiGLU backward with its gu pieces requested ahead)
+  w4_store<DT, EK, true>(g, smem, acc, m0, n0, 0);
 }
 
 template <int DT, bool AKS, bool BKS, int EK>
@@ -912,26 +901,49 @@ bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided) {
   return spanA < lim && spanB < lim;
 }
 
-// fp8 form: both operands K-contiguous bytes (g.K, lda, ldb in 2-byte units), no weight block exponents, plain / residual /
-// accumulating 16-bit epilogue, an even number of 128-byte K-tiles
+// fp8 form: both operands K-contiguous bytes (g.K, lda, ldb in 2-byte units), no weight block exponents, an even number of 128-byte K-tiles; epilogue
+// kinds: plain / residual / accumulating 16-bit store, fp32 store (lm_head), RoPE, SwiGLU forward and backward (all NT products in the fp8 step)
 bool w4_f8_can_run(const GemmArgs& g) {
-  const int e = g.epi & ~MH_EPI_ACCUM;
-  if (!(e == 0 || e == MH_EPI_RESIDUAL) || (g.epi & MH_EPI_OUT_F32) || !g.vec_ok || (g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
-  if (g.K % (2 * BK) != 0 || g.splits != 1 || g.rope_tab || g.sw_mode || g.sc_e) return false;
+  const int kind = w4_kind(g);
+  if (kind < 0 || kind == EK_F32ACC || !g.vec_ok) return false;
+  if (kind == EK_F32) {
+    if ((g.N % 4) || (g.ldc % 4) || ((((uintptr_t)g.C) & 15u) != 0)) return false;
+  } else if ((g.N % 8) || (g.ldc % 8) || ((((uintptr_t)g.C) & 15u) != 0)) {
+    return false;
+  }
+  if (g.K % (2 * BK) != 0 || g.splits != 1 || g.sc_e) return false;
+  if (kind == EK_ROPE && (g.rope_D != 128 || (g.rope_cols % 128) || g.rope_S <= 0)) return false;
+  if (kind == EK_SWIGLU && ((g.sw_ff % 8) || (g.sw_ldo % 8) || ((((uintptr_t)g.sw_out) & 15u) != 0))) return false;
+  if (kind == EK_SWIGLU_BWD && ((g.sw_ff % 8) || (g.sw_ldo % 8) || (g.sw_ldi % 8) || ((((uintptr_t)g.sw_out) | ((uintptr_t)g.sw_in)) & 15u) != 0 || g.N != g.sw_ff))
+    return false;
   if ((((uintptr_t)g.sc_n) & 15u) != 0 || (g.N % 4)) return false;
   const int64_t lim = (1ll << 32) - (1 << 20);
   return (int64_t)g.M * g.lda * 2 < lim && (int64_t)g.N * g.ldb * 2 < lim;
 }
-int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream) {
+bool w4_f8_is_fused(const GemmArgs& g) { const int k = w4_kind(g); return k == EK_ROPE || k == EK_SWIGLU || k == EK_SWIGLU_BWD || k == EK_F32; }
+template <int DT, int EK>
+static int launch_w4_f8(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_w4_f8<MH_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-    hipFuncSetAttribute((const void*)gemm_w4_f8<MH_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    hipFuncSetAttribute((const void*)gemm_w4_f8<DT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     attr_set = true;
   }
-  if (dt == MH_BF16) hipLaunchKernelGGL((gemm_w4_f8<MH_BF16>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
-  else hipLaunchKernelGGL((gemm_w4_f8<MH_F16>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
+  hipLaunchKernelGGL((gemm_w4_f8<DT, EK>), dim3(g.tiles_m * g.tiles_n), dim3(256), W4_LDS, stream, g);
   MH_LAUNCH_CHECK();
+}
+int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream) {
+  const int kind = w4_kind(g);
+#define F8_GO(EK_) return dt == MH_BF16 ? launch_w4_f8<MH_BF16, EK_>(g, stream) : launch_w4_f8<MH_F16, EK_>(g, stream)
+  switch (kind) {
+    case EK_STD: F8_GO(EK_STD);
+    case EK_F32: F8_GO(EK_F32);
+    case EK_ROPE: F8_GO(EK_ROPE);
+    case EK_SWIGLU: F8_GO(EK_SWIGLU);
+    case EK_SWIGLU_BWD: F8_GO(EK_SWIGLU_BWD);
+    default: break;
+  }
+#undef F8_GO
+  return MH_ERR_ARG;
 }
 
 // (instantiated: every layout for the plain kinds; the fused kinds in the layout their call sites have)

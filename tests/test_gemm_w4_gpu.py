@@ -154,3 +154,63 @@ def test_grouped_weight_gradients_of_a_clip_layer(ops, dtype, T, vd, vff):
     ops.wgrad_tn_grouped(acc, accum=True, force=True)
     for (_, _, got), (_, _, fresh), old in zip(acc, probs, olds):
         assert relerr(got, fresh.float() + old.float()) < 3 * EPS16[dtype]
+
+
+# ---- fp8 operands: the fused forms of the fp8 training step on the 4-wave fp8 kernel (gemm_w4_f8<EK>) -------------------------------------------
+def _deq(q8):
+    q, s = q8[0], q8[1]
+    return q.view(torch.float8_e4m3fn).float() * s[:, None]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_w4_fp8_fused_forms_vs_dequantised_fp32_and_the_8wave_kernel(ops, dtype):
+    """q|k|v + RoPE, gate|up + SwiGLU, the SwiGLU-backward dgrad and the fp32 logits store with e4m3 operands (per-row scales, exponent-free weights):
+    against the fp32 product of the DEQUANTISED operands followed by the fp32 element-wise op, and against the 8-wave fp8 kernel's staged forms."""
+    T, K, S, H, D, ff = 600, 512, 300, 2, 128, 640
+    x = rnd(T, K, dtype=dtype)
+    a8 = ops.quant_fp8_rows(x)
+    xa = _deq(a8)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    # q|k|v + RoPE
+    wq = rnd(3 * H * D, K, dtype=dtype, seed=1, scale=0.3)
+    w8 = ops.quant_fp8_rows(wq)
+    ref = (xa @ _deq(w8).t()).view(T, 3, H, D)
+    pos = torch.arange(T, device=dev()) % S
+    cos, sin = tab[pos, :, 0][:, None, :], tab[pos, :, 1][:, None, :]
+    want = ref.clone()
+    for part in (0, 1):
+        lo, hi = ref[:, part, :, :64], ref[:, part, :, 64:]
+        want[:, part] = torch.cat([lo * cos - hi * sin, hi * cos + lo * sin], -1)
+    want = want.view(T, -1)
+    g4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8_rope(a8, w8, tab, S, H, D, out_dtype=dtype))
+    g8 = _with_kernel(ops, 256, lambda: ops.gemm_fp8_rope(a8, w8, tab, S, H, D, out_dtype=dtype))
+    assert relerr(g4, want) < 3 * EPS16[dtype] and relerr(g4, g8.float()) < 3 * EPS16[dtype]
+    # gate|up + SwiGLU
+    wgu = rnd(2 * ff, K, dtype=dtype, seed=2, scale=0.3)
+    wgu8 = ops.quant_fp8_rows(wgu)
+    gu_ref = xa @ _deq(wgu8).t()
+    act_ref = torch.nn.functional.silu(gu_ref[:, :ff]) * gu_ref[:, ff:]
+    gu4, act4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8_swiglu_fwd(a8, wgu8, out_dtype=dtype))
+    gu8, act8 = _with_kernel(ops, 256, lambda: ops.gemm_fp8_swiglu_fwd(a8, wgu8, out_dtype=dtype))
+    assert relerr(gu4, gu_ref) < 3 * EPS16[dtype] and relerr(act4, act_ref) < 3 * EPS16[dtype]
+    assert relerr(gu4, gu8.float()) < 2 * EPS16[dtype] and relerr(act4, act8.float()) < 3 * EPS16[dtype]
+    # SwiGLU-backward dgrad: dy [T, d] x Wd^T [ff, d]
+    d = K
+    dy, wdT = rnd(T, d, dtype=dtype, seed=3, scale=0.5), rnd(ff, d, dtype=dtype, seed=4, scale=0.3)
+    dy8, wdT8 = ops.quant_fp8_rows(dy), ops.quant_fp8_rows(wdT)
+    gu = rnd(T, 2 * ff, dtype=dtype, seed=5)
+    g32, u32 = gu[:, :ff].float().requires_grad_(True), gu[:, ff:].float().requires_grad_(True)
+    (torch.nn.functional.silu(g32) * u32).backward(_deq(dy8) @ _deq(wdT8).t())
+    wantb = torch.cat([g32.grad, u32.grad], 1)
+    b4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8_swiglu_bwd(dy8, wdT8, gu))
+    b8 = _with_kernel(ops, 256, lambda: ops.gemm_fp8_swiglu_bwd(dy8, wdT8, gu))
+    assert relerr(b4, wantb) < 4 * EPS16[dtype] and relerr(b4, b8.float()) < 3 * EPS16[dtype]
+    # fp32 logits store
+    wl = rnd(1032, K, dtype=dtype, seed=6, scale=0.3)
+    wl8 = ops.quant_fp8_rows(wl)
+    lg4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8(a8, wl8, out=torch.empty(T, 1032, dtype=torch.float32, device=dev()), dt16=dtype))
+    assert relerr(lg4, xa @ _deq(wl8).t()) < 1e-4  # (fp32 store; the reference's own fp32 matmul order and the scale products differ by ~2e-5)
+    # plain + residual on the shared store phase
+    resid = rnd(T, 1032, dtype=dtype, seed=7)
+    r4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8(a8, wl8, out_dtype=dtype, resid=resid))
+    assert relerr(r4, xa @ _deq(wl8).t() + resid.float()) < 3 * EPS16[dtype]

@@ -9,15 +9,19 @@
 // third fewer LDS bytes per flop, one barrier pair per K-tile instead of eight, and every non-MFMA instruction of the loop
 // (fragment read, M0 write, LDS-DMA copy) sits behind its own MFMA in a hand-placed stream.  Measured where it is dispatched
 // (profiles/r03_gemm_w4_ab.txt): the TN weight gradients (K = 32 768 tokens: the per-tile fixed cost does not matter and the
-// 8-wave kernel's transpose-read phases were its slowest form).  The 8-wave kernel keeps the fused-epilogue GEMMs (RoPE,
-// SwiGLU), split-K, K tails and the small / short-K shapes: half as many waves share this kernel's epilogue.
+// 8-wave kernel's transpose-read phases were its slowest form).  Since round 4 it carries EVERY product of the decoder: the store
+// phase (w4_store) has one instantiation per epilogue kind - staged 16-bit store, fp32 store / accumulate, RoPE and SwiGLU on the
+// fp32 accumulators, SwiGLU backward - shared with the fp8 kernel below, split-K over grid.y, K tails of K-strided operands through
+// the buffer descriptor's range check, and a grouped launch for several weight gradients (profiles/r04_w4_forms_ab.txt).  The 8-wave
+// kernel keeps the CLIP tower's K = 1024 products (bias / quick-GELU forms) and contractions that are not whole 128-deep K-tile pairs.
 //
 // LDS = two K-tile buffers of 64 KiB: [A part 32 KiB | B part 32 KiB].
 //   K-contiguous part: [256 rows][128 B]; 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128).
 //   K-strided part (memory is [K][M]): two half-tiles [64 k][128 m] (256-B rows); the 32-byte column chunk is XORed with
 //   f(k) = (k & 3) | ((k >> 3) & 1) << 2, fragments come from `ds_read_b64_tr_b16` transpose-reads (two per fragment).
 //   Copies are LDS-DMA (`buffer_load_dwordx4 ... lds`, lane-linear LDS image => both swizzles are applied to the SOURCE
-//   address); per-lane byte offsets are loop-invariant VGPRs and the K advance is the scalar offset: no VALU per copy.
+//   address); per-lane byte offsets are loop-invariant VGPRs and the K advance is the scalar offset (K-contiguous operands) or the
+//   descriptor's base (K-strided operands: copy_ld): no VALU per copy.
 // Per K-tile t (fragment registers double-buffered per 32-deep k-step: set 0 = k 0..31, set 1 = k 32..63):
 //   phase E: 64 MFMAs on set 0 | read set 1 of tile t from buffer t&1; then lgkmcnt(0) + barrier B1 (every wave has all of
 //            tile t in registers: buffer t&1 is free) and the first copies of tile t+2 into buffer t&1

@@ -274,32 +274,66 @@ extern "C" int mh_gemm_swiglu_bwd(const void* dy, int64_t lddy, const void* Wd, 
 
 // ---- fp8 operands (e4m3 bytes, one fp32 scale per row of A and per row of B), scaled-fp8 MFMA ------------------------
 namespace {
-template <int DT>
+// NCH > 0: the row (K <= 512 * NCH elements) is requested once, every 16-byte piece of a lane before any is consumed, and both passes
+// (maximum, conversion) run on the packed registers; NCH = 0 walks the row twice with one dependent request per lane in flight.
+template <int DT, int NCH>
 __global__ __launch_bounds__(256) void quant_fp8_rows_k(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
                                                         int64_t ldq, float* __restrict__ sc, int R, int K) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const uint4* xr = (const uint4*)(x + (int64_t)row * ldx);
   const int nch = K >> 3;
-  float mx = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    float f[8];
-    unpack8<DT>(xr[c], f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
-  }
-  mx = wave_max(mx);
-  const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
-  const float inv = 1.0f / s;
-  if (lane == 0) sc[row] = s;
-  for (int c = lane; c < nch; c += 64) {
-    float f[8];
-    unpack8<DT>(xr[c], f);
+  auto emit = [&](int c, const float* f, float inv) {
     int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
     p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
     int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
     p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
     *(uint2*)(q + (int64_t)row * ldq + c * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+  };
+  float mx = 0.f;
+  if constexpr (NCH > 0) {
+    uint4 raw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      raw[j] = xr[min(c, nch - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float f[8];
+      unpack8<DT>(raw[j], f);  // (a clamped duplicate of the row's last piece changes no maximum)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+    }
+    mx = wave_max(mx);
+    const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) sc[row] = s;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float f[8];
+        unpack8<DT>(raw[j], f);
+        emit(c, f, inv);
+      }
+    }
+  } else {
+    for (int c = lane; c < nch; c += 64) {
+      float f[8];
+      unpack8<DT>(xr[c], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+    }
+    mx = wave_max(mx);
+    const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) sc[row] = s;
+    for (int c = lane; c < nch; c += 64) {
+      float f[8];
+      unpack8<DT>(xr[c], f);
+      emit(c, f, inv);
+    }
   }
 }
 }  // namespace
@@ -308,10 +342,12 @@ extern "C" int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ld
   if (!x || !q || !scales || R <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 7) || !aligned16(x) || (((uintptr_t)q) & 7u)) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   const dim3 grid((R + 3) / 4), block(256);
-  if (dt == MH_BF16)
-    hipLaunchKernelGGL(quant_fp8_rows_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, ldx, (uint8_t*)q, ldq, scales, R, K);
-  else
-    hipLaunchKernelGGL(quant_fp8_rows_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, ldx, (uint8_t*)q, ldq, scales, R, K);
+#define QR_GO(DT_, NCH_) \
+  hipLaunchKernelGGL((quant_fp8_rows_k<DT_, NCH_>), grid, block, 0, as_stream(stream), (const uint16_t*)x, ldx, (uint8_t*)q, ldq, scales, R, K)
+#define QR_DT(DT_) do { if (K <= 4096) QR_GO(DT_, 8); else if (K <= 12288) QR_GO(DT_, 24); else QR_GO(DT_, 0); } while (0)
+  if (dt == MH_BF16) QR_DT(MH_BF16); else QR_DT(MH_F16);
+#undef QR_DT
+#undef QR_GO
   MH_LAUNCH_CHECK();
 }
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_k(const uint16_t* __restr
 // RMSNorm forward that also emits the row-quantised e4m3 copy of its (16-bit rounded) output + the row scale: the operand of the
 // fp8 GEMM that follows, without a separate pass over y (BASELINE cfg 5: quantisation fused into the norm).  Bit-identical to
 // rmsnorm_fwd_k followed by quant_fp8_rows_k.  x and w are re-read from L1/L2 (a row is 8 KB), y and q are written once.
-template <int DT>
+template <int DT, int NCH = 0>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_q8_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
                                                         uint8_t* __restrict__ q, float* __restrict__ sc, int rows, int d, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,6 +106,55 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_q8_k(const uint16_t* __restri
   const uint4* wr = (const uint4*)w;
   uint4* yr = (uint4*)(y + (int64_t)row * d);
   const int nch = d >> 3;
+  if constexpr (NCH > 0) {
+    // d == 512 * NCH: x and w requested once, up front; the rounded outputs stay packed in registers between the passes
+    uint4 xq[NCH], wq[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      xq[j] = xr[lane + 64 * j];
+      wq[j] = wr[lane + 64 * j];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float f[8];
+      unpack8<DT>(xq[j], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)d + eps);
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float f[8], g[8];
+      unpack8<DT>(xq[j], f);
+      unpack8<DT>(wq[j], g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+      const uint4 pk = pack8<DT>(f);
+      yr[lane + 64 * j] = pk;
+      xq[j] = pk;  // the ROUNDED values are what the stand-alone quantiser sees
+      unpack8<DT>(pk, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+    }
+    mx = wave_max(mx);
+    const float s = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) sc[row] = s;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float f[8];
+      unpack8<DT>(xq[j], f);
+      int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+      p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
+      int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+      p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
+      *(uint2*)(q + (int64_t)row * d + (lane + 64 * j) * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+    }
+    return;
+  }
   float ss = 0.f;
   for (int c = lane; c < nch; c += 64) {
     float f[8];
@@ -192,7 +241,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restric
 // (x16 != NULL) the 16-bit copy of x that the backward keeps as the layer input.  Same arithmetic and summation order as
 // rmsnorm_fwd_k / layernorm_fwd_k; LN = true: LayerNorm (b != NULL).
 // Y32 = true: y is fp32 (the CLIP tower's pre_layrnorm writes the INITIAL value of the fp32 stream).
-template <int DT, bool LN, bool Y32 = false>
+// NCH > 0 (d == 512 * NCH: 4096 and 1024, the two widths of the model): the row is requested ONCE, all 2 * NCH float4 per lane
+// before anything is consumed, and the three passes run on registers - the generic form below (NCH = 0) walks the row three times
+// with one dependent 32-byte request per lane and pass in flight.
+template <int DT, bool LN, bool Y32 = false, int NCH = 0>
 __global__ __launch_bounds__(256) void norm_fwd_f32in_k(const float* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
                                                         uint16_t* __restrict__ y, uint16_t* __restrict__ x16, int rows, int d, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -204,6 +256,65 @@ __global__ __launch_bounds__(256) void norm_fwd_f32in_k(const float* __restrict_
   uint4* yr = (uint4*)(y + (int64_t)row * d);
   uint4* cr = x16 ? (uint4*)(x16 + (int64_t)row * d) : nullptr;
   const int nch = d >> 3;
+  if constexpr (NCH > 0) {
+    float4 xa[NCH], xe[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      xa[j] = xr[2 * c];
+      xe[j] = xr[2 * c + 1];
+    }
+    uint4 wq[NCH], bq[LN ? NCH : 1];  // requested now as well: a load in the last pass would wait behind that pass's stores (one vmcnt)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      wq[j] = wr[lane + 64 * j];
+      if constexpr (LN) bq[j] = br[lane + 64 * j];
+    }
+    float mu = 0.f;
+    if constexpr (LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const float4 a = xa[j], e = xe[j];
+        s += a.x; s += a.y; s += a.z; s += a.w; s += e.x; s += e.y; s += e.z; s += e.w;
+      }
+      mu = wave_sum(s) / (float)d;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const float4 a = xa[j], e = xe[j];
+      const float f[8] = {a.x, a.y, a.z, a.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += (f[i] - mu) * (f[i] - mu);
+    }
+    const float r = rsqrtf(wave_sum(ss) / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      const float4 a = xa[j], e = xe[j];
+      float f[8] = {a.x, a.y, a.z, a.w, e.x, e.y, e.z, e.w}, g[8];
+      if (cr) cr[c] = pack8<DT>(f);
+      unpack8<DT>(wq[j], g);
+      if constexpr (LN) {
+        float h[8];
+        unpack8<DT>(bq[j], h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (f[i] - mu) * r * g[i] + h[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = f[i] * r * g[i];
+      }
+      if constexpr (Y32) {
+        float4* y4 = (float4*)((float*)y + (int64_t)row * d);
+        y4[2 * c] = make_float4(f[0], f[1], f[2], f[3]);
+        y4[2 * c + 1] = make_float4(f[4], f[5], f[6], f[7]);
+      } else {
+        yr[c] = pack8<DT>(f);
+      }
+    }
+    return;
+  }
   float mu = 0.f;
   if constexpr (LN) {
     float s = 0.f;
@@ -539,11 +650,13 @@ extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
 extern "C" int mh_rmsnorm_fwd_q8(const void* x, const void* w, void* y, void* q, float* scales, int rows, int d, float eps, int dt, void* stream) {
   if (!x || !w || !y || !q || !scales || rows <= 0 || d <= 0 || (d & 7) || !aligned16(x) || !aligned16(w) || !aligned16(y) || (((uintptr_t)q) & 7u)) return MH_ERR_ARG;
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
-  if (dt == MH_BF16)
-    hipLaunchKernelGGL(rmsnorm_fwd_q8_k<MH_BF16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (uint8_t*)q, scales, rows, d, eps);
-  else if (dt == MH_F16)
-    hipLaunchKernelGGL(rmsnorm_fwd_q8_k<MH_F16>, grid, block, 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (uint8_t*)q, scales, rows, d, eps);
-  else return MH_ERR_DTYPE;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+#define Q8_GO(DT_, NCH_)                                                                                                                \
+  hipLaunchKernelGGL((rmsnorm_fwd_q8_k<DT_, NCH_>), grid, block, 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, \
+                     (uint8_t*)q, scales, rows, d, eps)
+  if (dt == MH_BF16) { if (d == 4096) Q8_GO(MH_BF16, 8); else Q8_GO(MH_BF16, 0); }
+  else { if (d == 4096) Q8_GO(MH_F16, 8); else Q8_GO(MH_F16, 0); }
+#undef Q8_GO
   MH_LAUNCH_CHECK();
 }
 
@@ -568,12 +681,15 @@ extern "C" int mh_norm_fwd_f32in(const float* x, const void* w, const void* b, v
   if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (b && !aligned16(b)) || (x16 && !aligned16(x16))) return MH_ERR_ARG;
   if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
   const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+#define NF32_GO_(DT_, LN_, NCH_)                                                                                                \
+  hipLaunchKernelGGL((norm_fwd_f32in_k<DT_, LN_, false, NCH_>), dim3(grid), dim3(256), 0, as_stream(stream), x, (const uint16_t*)w,   \
+                     (const uint16_t*)b, (uint16_t*)y, (uint16_t*)x16, rows, d, eps)
 #define NF32_GO(DT_, LN_)                                                                                                       \
-  hipLaunchKernelGGL((norm_fwd_f32in_k<DT_, LN_>), dim3(grid), dim3(256), 0, as_stream(stream), x, (const uint16_t*)w, (const uint16_t*)b, \
-                     (uint16_t*)y, (uint16_t*)x16, rows, d, eps)
+  do { if (d == 4096) NF32_GO_(DT_, LN_, 8); else if (d == 1024) NF32_GO_(DT_, LN_, 2); else NF32_GO_(DT_, LN_, 0); } while (0)
   if (dt == MH_BF16) { if (b) NF32_GO(MH_BF16, true); else NF32_GO(MH_BF16, false); }
   else { if (b) NF32_GO(MH_F16, true); else NF32_GO(MH_F16, false); }
 #undef NF32_GO
+#undef NF32_GO_
   MH_LAUNCH_CHECK();
 }
 

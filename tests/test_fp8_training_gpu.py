@@ -60,6 +60,26 @@ def test_fused_row_and_transposed_quantisation(dtype, R, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,K", [(301, 4096), (130, 11008), (77, 1000), (50, 12288), (33, 13312), (5, 8)])
+def test_row_quantisation_bytes_are_torch_e4m3_at_every_width_class(dtype, R, K):
+    """mh_quant_fp8_rows: widths up to 4096 and up to 12288 keep the row in registers (one request per row), wider rows take the two-pass
+    loop; in every class scale = max|row| / 448 and the bytes are torch's float8_e4m3fn rounding of row * (1 / scale); an all-zero row has
+    scale 1 and zero bytes."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(R + K)
+    x = (torch.randn(R, K, generator=g, device="cuda") * torch.rand(R, 1, generator=g, device="cuda") * 4).to(dtype)
+    x[R // 2] = 0
+    q, s = O.quant_fp8_rows(x)
+    amax = x.float().abs().amax(1)
+    s_ref = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    assert torch.allclose(s, s_ref, rtol=2e-7, atol=0)
+    q_ref = (x.float() * (1.0 / s)[:, None]).to(torch.float8_e4m3fn)  # the kernel multiplies by the reciprocal scale
+    assert torch.equal(q.view(torch.float8_e4m3fn).float(), q_ref.float())
+    assert int(q[R // 2].max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("R,C", [(300, 256), (4096, 1024)])
 def test_transposed_quantisation_with_tensor_scale(dtype, R, C):
     """The single-pass form of the training step: one scale for the whole tensor = the largest row scale of its row-quantised twin."""

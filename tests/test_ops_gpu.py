@@ -1147,3 +1147,23 @@ def test_fp32_stream_start_kernels(ops, dtype):
     want[sel] = feats32[src.view(-1)[sel].long()]
     assert out.dtype == torch.float32 and torch.equal(out, want)
     assert torch.equal(ops.embed_splice_fwd_f32(ids.view(-1), None, emb, None), emb.float()[ids.view(-1)])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,ln", [(4096, False), (1024, True), (4096, True), (1536, False), (1536, True)])
+def test_fp32_stream_reader_widths(ops, dtype, d, ln):
+    """The fp32 streams' reader (mh_norm_fwd_f32in) at the model's two widths - the register-resident forms, which request a row once - and
+    at a width that takes the generic three-pass loop: against torch in fp32; the 16-bit copy of the input is the rounded input exactly."""
+    rows = 37
+    x = torch.randn(rows, d, device=dev()) * 3 + 0.5
+    w = rnd(d, dtype=dtype, seed=1, scale=1.0)
+    b = rnd(d, dtype=dtype, seed=2, scale=1.0) if ln else None
+    y, x16 = ops.norm_fwd_f32in(x, w, 1e-5, b=b, want_x16=True)
+    if ln:
+        want = torch.nn.functional.layer_norm(x, (d,), w.float(), b.float(), 1e-5)
+    else:
+        want = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()
+    assert y.dtype == dtype and relerr(y, want) < 2 * EPS16[dtype]
+    assert torch.equal(x16, x.to(dtype))
+    y2, none = ops.norm_fwd_f32in(x, w, 1e-5, b=b)
+    assert none is None and torch.equal(y2, y)

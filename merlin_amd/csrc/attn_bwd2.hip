@@ -83,14 +83,15 @@ __device__ __forceinline__ void stream_row_frags(const unsigned* addr, F&& consu
   });
 }
 // transposed fragments of the 32-row half starting at tile row R0: fragment f = (d-block f/2, k-step f%2), NF = 2*DBLK
-template <int RB, int R0, int NF, typename F>
+// (XO: extra byte offset in the immediates - the stage of a double-buffered tile when the addresses are those of stage 0)
+template <int RB, int R0, int NF, int XO = 0, typename F>
 __device__ __forceinline__ void stream_tr_frags(const unsigned* addr, F&& consume) {
   u32x2_t w[8];  // window of 4 fragments
   constexpr int W = NF < 4 ? NF : 4;
   static_for<W>([&](auto I) {
     constexpr int f = decltype(I)::value;
-    lds_read64_tr<(R0 + (f % 2) * 16) * RB>(w[2 * f], addr[2 * (f / 2)]);
-    lds_read64_tr<(R0 + (f % 2) * 16 + 8) * RB>(w[2 * f + 1], addr[2 * (f / 2) + 1]);
+    lds_read64_tr<XO + (R0 + (f % 2) * 16) * RB>(w[2 * f], addr[2 * (f / 2)]);
+    lds_read64_tr<XO + (R0 + (f % 2) * 16 + 8) * RB>(w[2 * f + 1], addr[2 * (f / 2) + 1]);
   });
   static_for<NF>([&](auto I) {
     constexpr int f = decltype(I)::value;
@@ -100,8 +101,8 @@ __device__ __forceinline__ void stream_tr_frags(const unsigned* addr, F&& consum
     consume(I, fr);
     if constexpr (f + W < NF) {
       constexpr int g = f + W;
-      lds_read64_tr<(R0 + (g % 2) * 16) * RB>(w[2 * (f % W)], addr[2 * (g / 2)]);
-      lds_read64_tr<(R0 + (g % 2) * 16 + 8) * RB>(w[2 * (f % W) + 1], addr[2 * (g / 2) + 1]);
+      lds_read64_tr<XO + (R0 + (g % 2) * 16) * RB>(w[2 * (f % W)], addr[2 * (g / 2)]);
+      lds_read64_tr<XO + (R0 + (g % 2) * 16 + 8) * RB>(w[2 * (f % W) + 1], addr[2 * (g / 2) + 1]);
     }
   });
 }
@@ -246,35 +247,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
   const int ntiles = (kv_end + 63) / 64;
   const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
   const uint16_t* vbase = a.v + (int64_t)b * S * a.ldv + (int64_t)h * D;
-  auto stage = [&](int s, int kv0) {
-    char* base = smem + s * STAGE;
-    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave);
-    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave);
+  const unsigned lds0 = lds_addr_of(smem);
+  const auto src_k = row_src<D>(kbase, a.ldk, S, tid), src_v = row_src<D>(vbase, a.ldv, S, tid);
+  auto stage = [&](int s, int kv0) {  // scalar addressing only (attn_tiles.h, stage_rows_buf); rows >= S arrive as zeros and are masked
+    const unsigned base = lds0 + (unsigned)s * STAGE + (unsigned)wave * 1024u;
+    stage_rows_buf<D, 64>(src_k, kv0, base);
+    stage_rows_buf<D, 64>(src_v, kv0, base + T_BYTES);
   };
   f32x16_t dqacc[DBLK];
 #pragma unroll
   for (int i = 0; i < DBLK; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
-  const unsigned lds0 = lds_addr_of(smem);
   unsigned off_r[KSTEPS], off_t[KSTEPS];
   row_frag_offsets<D>(l31, hi, off_r);
   tr_frag_offsets<D>(lane, off_t);
   const float sc = a.scale_log2;
 
+  // (The forward's unrolled-by-two tile loop with the stage in the ds_read immediates does not fit here: 256 registers and spills of the Q / dO
+  // fragments inside the loop.  The V tile's addresses are the K tile's + T_BYTES in the immediates: 16 address adds per tile instead of 24.)
+  static_assert(T_BYTES + 32 * RB < 65536, "fragment offsets must fit the 16-bit ds_read immediate");
   auto tile = [&](int j, auto EDGE_) {
     constexpr bool EDGE = decltype(EDGE_)::value;
+    constexpr int SO = 0;
     const int kv0 = j * 64;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (j + 1 < ntiles) stage((j + 1) & 1, kv0 + 64);
     const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
-    unsigned ak[KSTEPS], av[KSTEPS], at[KSTEPS];
+    unsigned ak[KSTEPS], at[KSTEPS];
 #pragma unroll
     for (int i = 0; i < KSTEPS; ++i) {
       ak[i] = sb + off_r[i];
-      av[i] = sb + T_BYTES + off_r[i];
       at[i] = sb + off_t[i];
     }
     static_for<2>([&](auto HALF) {
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
       asm volatile("" : "+v"(nl_), "+v"(nd_));  // opaque: keeps hipcc from hoisting 32 registers of splatted initial values out of the loop
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sacc[r] = nl_; pacc[r] = nd_; }
-      stream_row_frags<hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, qf[decltype(I)::value], sacc); });
-      stream_row_frags<hf * 32 * RB, KSTEPS>(av, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, dof[decltype(I)::value], pacc); });
+      stream_row_frags<SO + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, qf[decltype(I)::value], sacc); });
+      stream_row_frags<SO + T_BYTES + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, dof[decltype(I)::value], pacc); });
       float dsv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(sacc[r] * sc);
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dsv[r] *= pacc[r];
       const u32x4_t dsf[2] = {pack8v<DT>(dsv), pack8v<DT>(dsv + 8)};
-      stream_tr_frags<RB, hf * 32, 2 * DBLK>(at, [&](auto I, const u32x4_t& fr) {
+      stream_tr_frags<RB, hf * 32, 2 * DBLK, SO>(at, [&](auto I, const u32x4_t& fr) {
         constexpr int f = decltype(I)::value;
         dqacc[f / 2] = mfma32v<DT>(fr, dsf[f % 2], dqacc[f / 2]);
       });
@@ -400,16 +405,12 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
   const uint16_t* dobase = a.dout + (int64_t)b * S * a.lddo + (int64_t)h * D;
   const float* lse_row = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
   const float* dl_row = a.delta + ((int64_t)b * a.H + h) * a.S_pad;
-  const auto so_q = stage_offsets<D, 64>(a.ldq, tid), so_do = stage_offsets<D, 64>(a.lddo, tid);
+  const auto src_q = row_src<D>(qbase, a.ldq, S, tid), src_do = row_src<D>(dobase, a.lddo, S, tid);
+  const unsigned lds_stage0 = lds_addr_of(smem) + (unsigned)wave * 1024u;
   auto stage = [&](int s, int q0) {
     char* base = smem + s * STAGE;
-    if constexpr (MODE == 2) {
-      stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave);
-      stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave);
-    } else {
-      stage_rows<D, 64>(qbase, a.ldq, q0, S - 1, base, tid, wave, so_q);
-      stage_rows<D, 64>(dobase, a.lddo, q0, S - 1, base + OFF_DO, tid, wave, so_do);
-    }
+    stage_rows_buf<D, 64>(src_q, q0, lds_stage0 + (unsigned)s * STAGE);  // scalar addressing only; rows >= S arrive as zeros and are masked
+    stage_rows_buf<D, 64>(src_do, q0, lds_stage0 + (unsigned)s * STAGE + OFF_DO);
     // per-wave copy: lanes 0-63 -> lse2[q0 + lane], then delta[q0 + lane] (2 x 256 contiguous LDS bytes)
     glds4(lse_row + q0 + lane, base + OFF_LSE + wave * 512);
     glds4(dl_row + q0 + lane, base + OFF_LSE + wave * 512 + 256);
@@ -667,6 +668,8 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
   using namespace mhattn;
   if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
+  for (int64_t ld_ : {ldq, ldk, ldv, lddo})
+    if ((int64_t)S * ld_ * 2 >= (1ll << 32)) return MH_ERR_SHAPE;  // one batch element's rows under a 32-bit num_records (stage_rows_buf)
   if (D != 128 && D != 64) return MH_ERR_SHAPE;
   Bwd2Args a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o;

@@ -75,11 +75,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   }
   const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
   const uint16_t* vbase = a.v + (int64_t)b * S * a.ldv + (int64_t)h * D;
-  const auto so_k = stage_offsets<D, 64>(a.ldk, tid), so_v = stage_offsets<D, 64>(a.ldv, tid);
-  auto stage = [&](int s, int kv0) {
-    char* base = smem + s * STAGE;
-    stage_rows<D, 64>(kbase, a.ldk, kv0, S - 1, base, tid, wave, so_k);
-    stage_rows<D, 64>(vbase, a.ldv, kv0, S - 1, base + T_BYTES, tid, wave, so_v);
+  const unsigned lds0 = lds_addr_of(smem);
+  const auto src_k = row_src<D>(kbase, a.ldk, S, tid), src_v = row_src<D>(vbase, a.ldv, S, tid);
+  auto stage = [&](int s, int kv0) {  // scalar addressing only (attn_tiles.h, stage_rows_buf); rows >= S arrive as zeros and are masked below
+    const unsigned base = lds0 + (unsigned)s * STAGE + (unsigned)wave * 1024u;
+    stage_rows_buf<D, 64>(src_k, kv0, base);
+    stage_rows_buf<D, 64>(src_v, kv0, base + T_BYTES);
   };
 
   f32x16_t o[DBLK];
@@ -90,29 +91,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   float m_run = -INFINITY, l_run = 0.f;
   const float sc = a.scale_log2;
 
-  const unsigned lds0 = lds_addr_of(smem);
   unsigned off_k[KSTEPS], off_v[KSTEPS];  // KSTEPS == 2*DBLK
   row_frag_offsets<D>(l31, hi, off_k);
   tr_frag_offsets<D>(lane, off_v);
 
   // One KV tile.  EDGE = false: the tile is fully visible to every wave of the block (no mask, no skip) - the
   // common case runs branch-free; EDGE = true: tiles on the causal diagonal / at the sequence end.
-  auto tile = [&](int j, auto EDGE_) {
+  // fragment addresses of stage 0; the stage a tile reads (PAR = j & 1, a template parameter: the tile loop is unrolled by two) goes into the
+  // ds_read immediates, so no address is computed per tile
+  unsigned ak[KSTEPS], av[KSTEPS];
+#pragma unroll
+  for (int i = 0; i < KSTEPS; ++i) {
+    ak[i] = lds0 + off_k[i];
+    av[i] = lds0 + T_BYTES + off_v[i];
+  }
+  static_assert(STAGE + T_BYTES + 56 * RB < 65536, "stage offset + fragment offset must fit the 16-bit ds_read immediate");
+  auto tile = [&](int j, auto EDGE_, auto PAR_) {
     constexpr bool EDGE = decltype(EDGE_)::value;
+    constexpr int SO = decltype(PAR_)::value * STAGE;  // byte offset of the stage this tile reads
     const int kv0 = j * 64;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < ntiles) stage((j + 1) & 1, kv0 + 64);
+    if (j + 1 < ntiles) stage(1 - decltype(PAR_)::value, kv0 + 64);
     if constexpr (EDGE) {
       if (CAUSAL && kv0 > qw0 + 31) return;  // tile entirely above this wave's diagonal (wave-uniform)
-    }
-    const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
-    unsigned ak[KSTEPS], av[KSTEPS];
-#pragma unroll
-    for (int i = 0; i < KSTEPS; ++i) {
-      ak[i] = sb + off_k[i];
-      av[i] = sb + T_BYTES + off_v[i];
     }
 
     // ---- S^T = K Q^T: fragment n = (key block n / KSTEPS, k-step n % KSTEPS), rolling window of WK reads ----
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
     u32x4_t wk[WK];
     static_for<WK>([&](auto I) {
       constexpr int n = decltype(I)::value;
-      lds_read128<(n / KSTEPS) * 32 * RB>(wk[n % WK], ak[n % KSTEPS]);
+      lds_read128<SO + (n / KSTEPS) * 32 * RB>(wk[n % WK], ak[n % KSTEPS]);
     });
     prio_mfma(true);
     static_for<NKF>([&](auto I) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
       constexpr int left = NKF - 1 - n;
       lgkm_wait<(left < WK - 1 ? left : WK - 1)>();
       st[n / KSTEPS] = mfma32v<DT>(wk[n % WK], qf[n % KSTEPS], st[n / KSTEPS]);
-      if constexpr (n + WK < NKF) lds_read128<((n + WK) / KSTEPS) * 32 * RB>(wk[n % WK], ak[(n + WK) % KSTEPS]);
+      if constexpr (n + WK < NKF) lds_read128<SO + ((n + WK) / KSTEPS) * 32 * RB>(wk[n % WK], ak[(n + WK) % KSTEPS]);
     });
 
     prio_mfma(false);
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
     u32x2_t wv[8];  // window of 4 fragments = 8 transpose-reads
     static_for<4>([&](auto I) {
       constexpr int f = decltype(I)::value;  // f = i*4 + s
-      lds_read64_tr<((f % 4) * 16) * RB>(wv[2 * f], av[2 * (f / 4)]);
-      lds_read64_tr<((f % 4) * 16 + 8) * RB>(wv[2 * f + 1], av[2 * (f / 4) + 1]);
+      lds_read64_tr<SO + ((f % 4) * 16) * RB>(wv[2 * f], av[2 * (f / 4)]);
+      lds_read64_tr<SO + ((f % 4) * 16 + 8) * RB>(wv[2 * f + 1], av[2 * (f / 4) + 1]);
     });
 
     // ---- mask (boundary tiles only), online softmax (one query row per lane; lane^32 holds the other 32 keys) ----
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
       o[f / 4] = mfma32v<DT>(vf, pf[f % 4], o[f / 4]);
       if constexpr (f + 4 < NVF) {
         constexpr int g = f + 4;
-        lds_read64_tr<((g % 4) * 16) * RB>(wv[2 * (f % 4)], av[2 * (g / 4)]);
-        lds_read64_tr<((g % 4) * 16 + 8) * RB>(wv[2 * (f % 4) + 1], av[2 * (g / 4) + 1]);
+        lds_read64_tr<SO + ((g % 4) * 16) * RB>(wv[2 * (f % 4)], av[2 * (g / 4)]);
+        lds_read64_tr<SO + ((g % 4) * 16 + 8) * RB>(wv[2 * (f % 4) + 1], av[2 * (g / 4) + 1]);
       }
     });
     prio_mfma(false);
@@ -216,8 +219,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   // tiles [0, n_full) need no masking for any wave of this block
   const int n_full = min(ntiles, CAUSAL ? min(q0, len) / 64 : len / 64);
   stage(0, 0);
-  for (int j = 0; j < n_full; ++j) tile(j, std::false_type{});
-  for (int j = n_full; j < ntiles; ++j) tile(j, std::true_type{});
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int j = 0;
+  for (; j + 1 < n_full; j += 2) {
+    tile(j, std::false_type{}, P0{});
+    tile(j + 1, std::false_type{}, P1{});
+  }
+  if (j < n_full) tile(j++, std::false_type{}, P0{});  // (j is even here)
+  for (; j < ntiles; ++j) {
+    if (j & 1) tile(j, std::true_type{}, P1{});
+    else tile(j, std::true_type{}, P0{});
+  }
 
   // ---- finalize ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -266,6 +279,7 @@ extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t l
   using namespace mhattn;
   if (!q || !k || !v || !o || !lse || B <= 0 || S <= 0 || H <= 0) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v)) return MH_ERR_ARG;
+  if ((int64_t)S * ldk * 2 >= (1ll << 32) || (int64_t)S * ldv * 2 >= (1ll << 32)) return MH_ERR_SHAPE;  // one batch element's rows under a 32-bit num_records
   if (g_attn_fwd_pingpong && D == 128 && (dt == MH_BF16 || dt == MH_F16))
     return launch_attn_fwd_pingpong(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
   Fwd2Args a;

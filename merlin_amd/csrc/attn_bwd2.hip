@@ -669,7 +669,7 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
   if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lddo & 7) || (ldo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3)) return MH_ERR_ARG;
   for (int64_t ld_ : {ldq, ldk, ldv, lddo})
-    if ((int64_t)S * ld_ * 2 >= (1ll << 32)) return MH_ERR_SHAPE;  // one batch element's rows under a 32-bit num_records (stage_rows_buf)
+    if ((int64_t)S * ld_ * 2 >= (1ll << 31)) return MH_ERR_SHAPE;  // one batch element under a 31-bit num_records (stage_rows_buf)
   if (D != 128 && D != 64) return MH_ERR_SHAPE;
   Bwd2Args a;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o;

@@ -279,7 +279,7 @@ extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t l
   using namespace mhattn;
   if (!q || !k || !v || !o || !lse || B <= 0 || S <= 0 || H <= 0) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v)) return MH_ERR_ARG;
-  if ((int64_t)S * ldk * 2 >= (1ll << 32) || (int64_t)S * ldv * 2 >= (1ll << 32)) return MH_ERR_SHAPE;  // one batch element's rows under a 32-bit num_records
+  if ((int64_t)S * ldk * 2 >= (1ll << 31) || (int64_t)S * ldv * 2 >= (1ll << 31)) return MH_ERR_SHAPE;  // one batch element under a 31-bit num_records (stage_rows_buf)
   if (g_attn_fwd_pingpong && D == 128 && (dt == MH_BF16 || dt == MH_F16))
     return launch_attn_fwd_pingpong(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
   Fwd2Args a;

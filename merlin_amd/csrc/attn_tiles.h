@@ -140,11 +140,13 @@ __device__ __forceinline__ void stage_rows(const uint16_t* gbase, int64_t ld, in
 // ---- the same tile copy through a buffer descriptor: NO vector arithmetic per tile --------------------------------------------------------
 // The copies above keep one 64-bit pointer per thread and copy (or re-derive it, clamped, with quarter-rate multiplies) and advance all of
 // them every tile - 16-24 64-bit VALU operations per K|V tile in a loop whose VALU stream is as long as its MFMA stream.  Here the tile's
-// position is entirely scalar: a descriptor whose BASE is the tile's first row (64-bit SALU add) and whose num_records ends at the last row
-// of this batch element, so rows past the end read as ZEROS (every kernel masks them; the clamped copies of the last row the forms above
-// deliver needed the same masks).  The per-thread part is ONE register: thread t of a copy instruction takes 16-byte chunk (t % CPR) ^ swz
-// of row t / CPR, and instruction i of a tile adds i * RPL rows - a scalar (soffset), because the swizzle only sees row % 16 and RPL is a
-// multiple of 16.  (Only the descriptor's base + voffset are range-checked, soffset is not: hence the moving base.)
+// position is entirely scalar: a descriptor whose BASE is the tile's first row (64-bit SALU add).  The per-thread part is ONE register:
+// thread t of a copy instruction takes 16-byte chunk (t % CPR) ^ swz of row t / CPR, and instruction i of a tile adds i * RPL rows - a scalar
+// (soffset), because the swizzle only sees row % 16 and RPL is a multiple of 16.
+// Rows past the end of the batch element (the last tile of a sequence whose length is not a multiple of the tile) must not be READ - beyond
+// the last batch element lies memory that is not ours - and arrive as ZEROS (every kernel masks them; the clamped copies of the last row the
+// forms above deliver needed the same masks).  The hardware checks base + voffset against num_records but NOT soffset, so that tile takes one
+// descriptor per copy instruction: base at the instruction's first row, num_records = what is left of the batch element from there.
 // M0 is saved and restored inside the statement (hipcc owns it: the backward kernels' global_load_lds builtins set it too); `s_nop 4` opens
 // the statement for the case that hipcc produced one of the scalar operands with v_readfirstlane (cdna guide, inline asm item 2).
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -152,7 +154,8 @@ template <int D>
 struct RowSrc {
   uint64_t base;       // byte address of (row 0, col 0) of this (batch, head)
   unsigned row_bytes;  // row stride in bytes
-  unsigned span;       // bytes from base to the end of the batch element's last row = S * row_bytes
+  unsigned span;       // bytes from base to the end of the batch element's last row = rows * row_bytes (< 2^31, checked by the launchers)
+  int rows;            // rows of the batch element (S)
   unsigned voff;       // this thread's byte offset inside a copy instruction's row group
   unsigned step[3];    // soffset of copy instructions 1..3 of a tile
 };
@@ -162,6 +165,7 @@ __device__ __forceinline__ RowSrc<D> row_src(const uint16_t* gbase, int64_t ld, 
   RowSrc<D> r;
   r.base = (uint64_t)(uintptr_t)gbase;
   r.row_bytes = (unsigned)ld * 2u;
+  r.rows = S;
   r.span = (unsigned)S * r.row_bytes;
   const int row = tid / CPR, cc = tid % CPR;
   r.voff = (unsigned)row * r.row_bytes + (unsigned)((cc ^ TileSwz<D>::f(row)) * 16);
@@ -169,36 +173,51 @@ __device__ __forceinline__ RowSrc<D> row_src(const uint16_t* gbase, int64_t ld, 
   for (int i = 0; i < 3; ++i) r.step[i] = (unsigned)((i + 1) * RPL) * r.row_bytes;
   return r;
 }
-// lds_wave = LDS byte address of the tile + wave * 1024 (wave-uniform); r0 = first row of the tile (wave-uniform, < S)
+__device__ __forceinline__ i32x4_t row_srd(uint64_t base, unsigned nrec) {
+  return i32x4_t{(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)nrec, 0x00020000};
+}
+// lds_wave = LDS byte address of the tile + wave * 1024 (wave-uniform); r0 = first row of the tile (wave-uniform, < rows)
 template <int D, int ROWS>
 __device__ __forceinline__ void stage_rows_buf(const RowSrc<D>& src, int r0, unsigned lds_wave) {
   constexpr int NLD = ROWS * (D / 8) / 256;
   static_assert(NLD == 2 || NLD == 4, "64-row tiles of D = 64 / 128");
   const unsigned adv = (unsigned)r0 * src.row_bytes;
-  const uint64_t bt = src.base + adv;
-  const long long left = (long long)src.span - (long long)adv;
-  i32x4_t rs = {(int)(uint32_t)bt, (int)(uint32_t)((bt >> 32) & 0xffffu), (int)(left > 0 ? left : 0), 0x00020000};
   unsigned keep;
-  if constexpr (NLD == 4) {
-    asm volatile(
-        "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-        "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-        "s_add_u32 m0, %3, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %5 offen lds\n\t"
-        "s_add_u32 m0, %3, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %6 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src.voff), "s"(rs), "s"(lds_wave), "s"(src.step[0]), "s"(src.step[1]), "s"(src.step[2])
-        : "memory", "scc");
-  } else {
-    asm volatile(
-        "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-        "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src.voff), "s"(rs), "s"(lds_wave), "s"(src.step[0])
-        : "memory", "scc");
+  if (r0 + ROWS <= src.rows) {  // wave-uniform; every row of the tile exists: one descriptor, nothing to clamp
+    const i32x4_t rs = row_srd(src.base + adv, src.span - adv);
+    if constexpr (NLD == 4) {
+      asm volatile(
+          "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+          "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+          "s_add_u32 m0, %3, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %5 offen lds\n\t"
+          "s_add_u32 m0, %3, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %6 offen lds\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src.voff), "s"(rs), "s"(lds_wave), "s"(src.step[0]), "s"(src.step[1]), "s"(src.step[2])
+          : "memory", "scc");
+    } else {
+      asm volatile(
+          "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+          "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src.voff), "s"(rs), "s"(lds_wave), "s"(src.step[0])
+          : "memory", "scc");
+    }
+  } else {  // the sequence's last, partial tile: one descriptor per copy instruction (range-checked row by row)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const unsigned adv_i = adv + (i ? src.step[i - 1] : 0u);
+      const long long left = (long long)src.span - (long long)adv_i;
+      const i32x4_t rs = row_srd(src.base + adv_i, left > 0 ? (unsigned)left : 0u);
+      const unsigned dst = lds_wave + (unsigned)i * 0x1000u;
+      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src.voff), "s"(rs), "s"(dst)
+                   : "memory");
+    }
   }
 }
 

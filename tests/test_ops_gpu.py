@@ -280,6 +280,36 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,D,causal", [(1, 577, 2, 64, False), (2, 300, 2, 128, True), (1, 613, 1, 128, True), (1, 70, 2, 128, True), (1, 17, 2, 64, False)])
+def test_attention_never_reads_rows_past_the_batch(ops, dtype, B, S, H, D, causal):
+    """The K|V / Q|dO tile copies go through buffer descriptors (csrc/attn_tiles.h stage_rows_buf): rows past the end of a batch element
+    - the tail of a sequence's last, partial tile - must read as zeros whatever lies behind them in memory.  q, k, v, dO here are views of a
+    buffer with 64 more rows of NaN behind the last batch element; a kernel that read one of them (NaN x 0 in an MFMA) would return NaN.
+    The results must be those of the same tensors with a clean tail, bit for bit."""
+    T = B * S
+    g = torch.Generator(device="cuda").manual_seed(S)
+    clean = torch.randn(T + 64, 3 * H * D, generator=g, device=dev()).to(dtype)
+    clean[T:] = 0
+    dirty = clean.clone()
+    dirty[T:] = float("nan")
+    do_c = torch.randn(T + 64, H * D, generator=g, device=dev()).to(dtype)
+    do_c[T:] = 0
+    do_d = do_c.clone()
+    do_d[T:] = float("nan")
+
+    def run(buf, dob):
+        q, k, v = (buf[:T, i * H * D:(i + 1) * H * D] for i in range(3))
+        o, lse = ops.attn_fwd2(q, k, v, B, S, H, D, causal)
+        dq, dk, dv = ops.attn_bwd2(q, k, v, o, dob[:T], lse, B, S, H, D, causal)
+        return o, dq, dk, dv
+
+    a, b = run(clean, do_c), run(dirty, do_d)
+    for x, y, name in zip(a, b, ("o", "dq", "dk", "dv")):
+        assert torch.isfinite(y.float()).all(), name
+        assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_patch_embed_pieces(ops, dtype):
     N, img, ps, d = 3, 56, 14, 128
     G = img // ps

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
   const int64_t bh = (int64_t)b * a.H + h;
   const float nls = a.lse2[bh * a.S_pad + min(qrow, S - 1)];   // -lse/scale
   const float ndl = a.delta[bh * a.S_pad + min(qrow, S - 1)];  // -delta
+  const float nlb = nls * a.scale_log2;                          // -lse * log2(e)
   const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
   const int ntiles = (kv_end + 63) / 64;
   const uint16_t* kbase = a.k + (int64_t)b * S * a.ldk + (int64_t)h * D;
@@ -288,16 +289,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
       if constexpr (EDGE) {
         if ((CAUSAL && kvh > qw0 + 31) || kvh >= len) return;  // nothing visible to this wave (wave-uniform)
       }
+      // Both chains start from the MFMA's inline-constant zero C operand (no accumulator to initialise: the -lse / -delta splats of the
+      // round-3 form were 32 v_mov per half); the row constants enter in the element work instead: p = exp2(s * sc - lse * log2e) as one fma
+      // per score, dS = p * (dP - delta).
       f32x16_t sacc, pacc;
-      float nl_ = nls, nd_ = ndl;
-      asm volatile("" : "+v"(nl_), "+v"(nd_));  // opaque: keeps hipcc from hoisting 32 registers of splatted initial values out of the loop
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = nl_; pacc[r] = nd_; }
-      stream_row_frags<SO + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { sacc = mfma32v<DT>(fr, qf[decltype(I)::value], sacc); });
-      stream_row_frags<SO + T_BYTES + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) { pacc = mfma32v<DT>(fr, dof[decltype(I)::value], pacc); });
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      stream_row_frags<SO + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) {
+        constexpr int n = decltype(I)::value;
+        if constexpr (n == 0) sacc = mfma32v<DT>(fr, qf[0], zero);
+        else sacc = mfma32v<DT>(fr, qf[n], sacc);
+      });
+      stream_row_frags<SO + T_BYTES + hf * 32 * RB, KSTEPS>(ak, [&](auto I, const u32x4_t& fr) {
+        constexpr int n = decltype(I)::value;
+        if constexpr (n == 0) pacc = mfma32v<DT>(fr, dof[0], zero);
+        else pacc = mfma32v<DT>(fr, dof[n], pacc);
+      });
       float dsv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(sacc[r] * sc);
+      for (int r = 0; r < 16; ++r) dsv[r] = fast_exp2(fmaf(sacc[r], sc, nlb));
       if (EDGE && ((kvh + 32 > len) || (qw0 + 32 > len) || (CAUSAL && (kvh + 31 > qw0)))) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsv[r] *= pacc[r];
+      for (int r = 0; r < 16; ++r) dsv[r] *= pacc[r] + ndl;
       const u32x4_t dsf[2] = {pack8v<DT>(dsv), pack8v<DT>(dsv + 8)};
       stream_tr_frags<RB, hf * 32, 2 * DBLK, SO>(at, [&](auto I, const u32x4_t& fr) {
         constexpr int f = decltype(I)::value;

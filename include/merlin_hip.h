@@ -248,8 +248,10 @@ int mh_rope_qk(void* qkv, const float* cos_sin, int T, int S, int H, int D, int 
 int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                  float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt, void* stream);
 /* D = 128: 1 = the forward runs in its PING-PONG form (csrc/attn_fwd3.hip: 8-wave 256-query blocks, the two waves of a SIMD held in
- * opposite phases - one in its MFMA section while the other is in its softmax section), 0 (default) = two free-running 128-query
- * blocks per CU (attn_fwd2.hip).  A-B switch; identical results. */
+ * opposite phases - one in its MFMA section while the other is in its softmax section), 2 = ONE WAVE PER SIMD with 64 query rows per
+ * wave (csrc/attn_fwd4.hip: K fragments resident in AccVGPRs, the softmax of one 32-row half between the MFMAs of the other),
+ * 0 (default) = two free-running 128-query blocks per CU (attn_fwd2.hip).  A-B switch; bit-identical results
+ * (profiles/r03_attn_fwd_pingpong.txt, profiles/r04_attn_fwd_wave64.txt). */
 void mh_attn_fwd_pingpong(int on);
 /* Backward: dq/dk/dv are [B*S, H, D] views with their own row strides; no workspace and no operand re-layout passes
  * (transposed operands come from LDS transpose-reads); rope_cos_sin != NULL applies the inverse RoPE to dq, dk.  `delta`: ZERO-INITIALISED fp32 scratch of 2*B*H*S_pad floats. */

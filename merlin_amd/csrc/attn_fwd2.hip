@@ -269,9 +269,11 @@ int launch_fwd2(const Fwd2Args& a, hipStream_t st) {
 namespace mhattn {
 int launch_attn_fwd_pingpong(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
                          const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st);  // attn_fwd3.hip
-int g_attn_fwd_pingpong = 0;
+int launch_attn_fwd_wave64(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
+                           const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st);  // attn_fwd4.hip
+int g_attn_fwd_pingpong = 0;  // D = 128 forward form: 0 = attn_fwd2 (default), 1 = attn_fwd3 (ping-pong), 2 = attn_fwd4 (one wave per SIMD, 64 rows per wave)
 }  // namespace mhattn
-extern "C" void mh_attn_fwd_pingpong(int on) { mhattn::g_attn_fwd_pingpong = on ? 1 : 0; }
+extern "C" void mh_attn_fwd_pingpong(int on) { mhattn::g_attn_fwd_pingpong = (on == 2) ? 2 : (on ? 1 : 0); }
 
 extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                             int64_t ldo, float* lse, const int32_t* seqlens, int B, int S, int H, int D, int causal, int dt,
@@ -280,6 +282,8 @@ extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t l
   if (!q || !k || !v || !o || !lse || B <= 0 || S <= 0 || H <= 0) return MH_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v)) return MH_ERR_ARG;
   if ((int64_t)S * ldk * 2 >= (1ll << 31) || (int64_t)S * ldv * 2 >= (1ll << 31)) return MH_ERR_SHAPE;  // one batch element under a 31-bit num_records (stage_rows_buf)
+  if (g_attn_fwd_pingpong == 2 && D == 128 && (dt == MH_BF16 || dt == MH_F16))
+    return launch_attn_fwd_wave64(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
   if (g_attn_fwd_pingpong && D == 128 && (dt == MH_BF16 || dt == MH_F16))
     return launch_attn_fwd_pingpong(q, ldq, k, ldk, v, ldv, o, ldo, lse, seqlens, B, S, H, causal, dt, as_stream(stream));
   Fwd2Args a;

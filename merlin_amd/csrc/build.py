@@ -17,7 +17,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm_w4.hip", "norm.hip", "elementwise.hip", "attn_fwd2.hip", "attn_fwd3.hip", "attn_bwd2.hip", "loss_splice.hip", "conv.hip", "decode.hip", "sampling.hip", "fp8_quant.hip", "parity32.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm_w4.hip", "norm.hip", "elementwise.hip", "attn_fwd2.hip", "attn_fwd3.hip", "attn_fwd4.hip", "attn_bwd2.hip", "loss_splice.hip", "conv.hip", "decode.hip", "sampling.hip", "fp8_quant.hip", "parity32.hip"]
 DEV_DIR = os.path.normpath(os.path.join(HERE, "..", "..", "tools", "dev_arms"))
 DEV_SOURCES = ["gemm256_m32.hip", "gemm256w4.hip", "gemm256w8.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_bwd_kv.hip"]
 DEV_LIB = os.path.join(DEV_DIR, "libmerlin_hip_dev.so")

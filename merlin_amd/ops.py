@@ -1097,8 +1097,9 @@ def gemv_mfma_wide(on: bool):
     L.lib().mh_gemv_mfma_wide(i32(1 if on else 0))
 
 
-def attn_fwd_pingpong(on: bool):
-    """A/B switch: D = 128 attention forward in the ping-pong form (8-wave blocks, SIMD partners in opposite phases; csrc/attn_fwd3.hip)."""
+def attn_fwd_pingpong(on):
+    """A/B switch of the D = 128 attention forward: 0 / False = attn_fwd2 (default), 1 / True = the ping-pong form (8-wave blocks, SIMD partners in
+    opposite phases; csrc/attn_fwd3.hip), 2 = one wave per SIMD with 64 query rows per wave (csrc/attn_fwd4.hip)."""
     L.lib().mh_attn_fwd_pingpong(i32(int(on)))
 
 

@@ -1025,6 +1025,36 @@ def test_gemm_fp8_fused_rope_and_swiglu_match_unfused(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,H,causal,ragged", [(2, 256, 2, True, False), (1, 1000, 3, True, False), (2, 613, 2, True, True), (1, 1536, 2, False, False),
+                                                  (3, 700, 1, False, True), (1, 4096, 2, True, False), (2, 2432, 1, True, True), (1, 64, 1, True, False),
+                                                  (2, 130, 1, True, True), (1, 320, 2, False, False)])
+def test_attention_forward_one_wave_per_simd_form_is_bit_identical(ops, dtype, B, S, H, causal, ragged):
+    """csrc/attn_fwd4.hip (mh_attn_fwd_pingpong(2): 4 waves x 64 query rows, one wave per SIMD, K fragments resident in AccVGPRs, the softmax of
+    one 32-row half placed between the MFMAs of the other) performs the per-row arithmetic of attn_fwd2 in the same order: outputs and
+    log-sum-exps must agree BIT FOR BIT - causal and not, ragged lengths, sequence lengths that are not a multiple of the 256-row block,
+    a single tile, padded rows zero."""
+    D = 128
+    g = torch.Generator(device="cuda").manual_seed(S + H)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g, device="cuda") * 0.7).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    lens = None
+    if ragged:
+        lens = torch.tensor([max(1, S - 37 * (b + 1) - (b * 211) % S // 3) for b in range(B)], dtype=torch.int32, device="cuda")
+    try:
+        ops.attn_fwd_pingpong(0)
+        o0, l0 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+        ops.attn_fwd_pingpong(2)
+        o1, l1 = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+        o2, _ = ops.attn_fwd2(q, k, v, B, S, H, D, causal, seqlens=lens)
+    finally:
+        ops.attn_fwd_pingpong(0)
+    assert torch.equal(o1, o2)  # deterministic
+    assert torch.isfinite(o1.float()).all()
+    assert torch.equal(o1, o0), relerr(o1, o0.float())
+    assert torch.equal(l1[:, :, :S], l0[:, :, :S])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,causal,ragged", [(2, 256, 2, True, False), (1, 1000, 3, True, False), (2, 613, 2, True, True), (1, 1536, 2, False, False),
                                                   (3, 700, 1, False, True), (1, 4096, 2, True, False), (2, 2432, 1, True, True)])
 def test_attention_forward_pingpong_form_matches(ops, dtype, B, S, H, causal, ragged):
     """csrc/attn_fwd3.hip (mh_attn_fwd_pingpong(1): 8-wave 256-query blocks, SIMD partners in opposite phases) against the 128-query form

@@ -39,6 +39,10 @@ def run(B, S, H, D, causal, seqlens=None, tag=""):
 
 if __name__ == "__main__":
     print("library:", os.environ.get("MH_LIB_PATH", "product"))
+    form = int(os.environ.get("MH_ATTN_FWD_FORM", "0"))  # 0: attn_fwd2 (default), 1: attn_fwd3 (ping-pong), 2: attn_fwd4 (one wave per SIMD)
+    if form:
+        O.attn_fwd_pingpong(form)
+        print("forward form:", form)
     for _ in range(2):
         run(8, 4096, 32, 128, True, tag="cfg3")
         run(4, 8192, 32, 128, True, tag="cfg5")

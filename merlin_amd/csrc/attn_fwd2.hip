@@ -219,6 +219,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   // tiles [0, n_full) need no masking for any wave of this block
   const int n_full = min(ntiles, CAUSAL ? min(q0, len) / 64 : len / 64);
   stage(0, 0);
+  // The Q fragments (plain global loads, waited for by hipcc) are USED here, once: left to their first use - inside the tile loop - hipcc
+  // keeps a counted `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the first eight MFMAs of EVERY tile, and that counter also holds the
+  // eight LDS-DMA copies of the next tile requested just above them: each wave sat out the whole copy it had just requested before it
+  // finished its first score chain (the prefetch overlapped nothing within the wave).  Here the wait covers Q and tile 0 together.
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   int j = 0;

@@ -36,10 +36,14 @@ def main():
     last_write = {}  # reg -> (instr index, line no) of the last non-MFMA VALU write
     idx = 0
     bad = 0
+    seen_kernel = sel is None
     for ln, raw in enumerate(text, 1):
-        if sel is not None and raw.startswith("_Z") and raw.rstrip().endswith(":"):
-            inside = sel in raw
+        m = re.match(r"^(_Z\w+):", raw)
+        if sel is not None and m:
+            inside = sel == m.group(1) or sel in m.group(1)
             pending, nm = [], 0
+            if inside:
+                seen_kernel = True
         if not inside:
             continue
         p = parse(raw)
@@ -76,6 +80,9 @@ def main():
         if op.startswith("v_"):
             for r in wr:
                 last_write[r] = (idx, ln)
+    if not seen_kernel:
+        print("kernel not found:", sel)
+        sys.exit(2)
     print("hazards:", bad)
 
 

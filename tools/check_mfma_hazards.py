@@ -50,8 +50,9 @@ def main():
         if p is None:
             continue
         op, ops = p
-        if op == "s_endpgm":
+        if op in ("s_endpgm", "s_branch", "s_setpc_b64"):  # the next instruction in the listing is not reached from here
             pending = []
+            last_write = {}
             continue
         if op.startswith("s_nop"):
             m = re.search(r"s_nop\s+(\d+)", raw)
@@ -80,6 +81,8 @@ def main():
         if op.startswith("v_"):
             for r in wr:
                 last_write[r] = (idx, ln)
+            # a register rewritten by this instruction no longer holds the MFMA's (late) result as far as later READERS are concerned
+            pending = [(d - wr, c, l, i0) for (d, c, l, i0) in pending]
     if not seen_kernel:
         print("kernel not found:", sel)
         sys.exit(2)

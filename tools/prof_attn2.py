@@ -10,6 +10,9 @@ qkv = (torch.randn(B * S, 3 * H * D, device=dev) * 0.5).bfloat16()
 q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
 do = torch.randn(B * S, H * D, device=dev).bfloat16()
 dqkv = torch.empty_like(qkv)
+form = int(os.environ.get("MH_ATTN_FWD_FORM", "0"))  # 0: attn_fwd2 (default), 1: attn_fwd3, 2: attn_fwd4
+if form:
+    O.attn_fwd_pingpong(form)
 o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=causal)
 for _ in range(2):
     O.attn_fwd2(q, k, v, B, S, H, D, causal=causal, out=o, lse=lse)

@@ -260,6 +260,11 @@ int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
                  void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt, void* stream);
 /* dK and dV from one kernel (scores and dP computed once per tile; default) or from two (0): A/B switch. */
 void mh_attn_bwd_fused_kv(int on);
+/* The row-per-lane epilogues of the attention kernels (o; dq, dk, dv) write 16 bytes per lane after a half-wave exchange (default, needs
+ * 16-byte aligned rows: ld % 8 == 0) instead of 8 (0): A/B switch, bit-identical results (profiles/r05_attn_wide_stores.txt).
+ * Limits of mh_attn_fwd2 / mh_attn_bwd2: one batch element's rows of q / k / v / dout must span < 2^31 bytes (S * ld * 2 < 2^31: the
+ * tile copies use a 31-bit buffer-descriptor range; MH_ERR_SHAPE otherwise - with fused q|k|v rows of 3 * 4096 channels that is S < 87 381). */
+void mh_attn_wide_stores(int on);
 /* ---- KV-cache decode (S_q = 1): generate() behind llama_mmgpt.py:114-134 / eval_mmvet.py:101-120 ------------------
  * HF LlamaAttention with past_key_values (modeling_llama.py:243-281): q,k of the new token rotated at its own
  * position, k,v appended to the cache, softmax(q K^T / sqrt(D)) V over keys [0, len).  All HBM-bound kernels. */
@@ -439,6 +444,10 @@ int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream);
 /* Deterministic form (fixed grid, fixed-order two-stage sum; 16-byte loads): out[0] = sum g^2; `partial` = 2048 floats
  * of scratch.  Used for gradient clipping so that the clip coefficient - and therefore training - is run-to-run reproducible. */
 int mh_sumsq_det(const void* g, int64_t n, float* partial, float* out, int dt, void* stream);
+/* *flag |= 1 when any of the n 16-bit elements (bf16 or fp16, 16-byte aligned) has a non-zero magnitude: an exact test on the bit patterns
+ * (-0 counts as zero; NaN, Inf and values whose square underflows fp32 do not).  merlin_amd/dp.py uses it before it lets a backward
+ * accumulate onto an attached gradient arena that was already all-reduced (`zero_grad(set_to_none=False)` workflows). */
+int mh_any_nonzero(const void* g, int64_t n, int* flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,11 @@
 #include "attn_tiles.h"
 
 namespace mhattn {
+#ifdef MH_KV_TIMING
+int g_attn_wide_stores = 1;  // (stand-alone probe build of this file)
+#else
+extern int g_attn_wide_stores;  // attn_fwd2.hip (mh_attn_wide_stores)
+#endif
 namespace {
 
 struct Bwd2Args {
@@ -33,7 +38,17 @@ struct Bwd2Args {
   int B, S, H, S_pad;
   float scale, scale_log2, inv_scale;
   const float2* rope;  // optional: inverse RoPE (rotate-half) of dQ and dK rows at their sequence position, fused into the epilogues
+  int wide;            // dq / dk / dv rows are 16-byte aligned: 16-byte epilogue stores (attn_tiles.h, store_row_wide)
+#ifdef MH_KV_TIMING
+  unsigned long long* dbg;  // development build (tools/probes/kv_timing.py): [block][wave][8] cycles per tile segment of the fused dK|dV kernel
+#endif
 };
+#ifdef MH_KV_TIMING
+// s_memtime returns through lgkmcnt: the stamps sit only where the tile's own LDS reads have all been consumed
+#define KV_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tacc[i] += t_ - tprev; tprev = t_; }
+#else
+#define KV_STAMP(i)
+#endif
 
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
@@ -341,16 +356,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_dq_k(Bwd2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqacc[i][r] *= a.scale;
     if (a.rope && valid) unrope_rows<D>(dqacc, a.rope + (int64_t)qrow * (D / 2), hi);
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * i + 8 * g + 4 * hi;
-        uint2 w = make_uint2(0, 0);
-        if (valid)
-          w = make_uint2(pack2<DT>(dqacc[i][4 * g + 0], dqacc[i][4 * g + 1]), pack2<DT>(dqacc[i][4 * g + 2], dqacc[i][4 * g + 3]));
-        *(uint2*)(dqp + d) = w;
-      }
+    auto val = [&](int i, int r) { return dqacc[i][r]; };
+    if (a.wide) store_row_wide<DT, DBLK>(dqp, hi, valid, val);
+    else store_row_narrow<DT, DBLK>(dqp, hi, valid, val);
   }
 }
 
@@ -438,13 +446,18 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
   tr_frag_offsets<D>(lane, off_t);
   const unsigned off_l = OFF_LSE + wave * 512 + hi * 16;
   const float sc = a.scale_log2;
+#ifdef MH_KV_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
 
   auto tile = [&](int j, auto EDGE_) {
     constexpr bool EDGE = decltype(EDGE_)::value;
     const int q0 = q_begin + j * 64;
+    if constexpr (MODE == 3 && !EDGE) { KV_STAMP(0); }  // [0] the previous tile's last segment (D), or everything before the first full tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE == 3 && !EDGE) { KV_STAMP(1); }  // [1] vmcnt(0) + barrier
     if (j + 1 < ntiles) stage((j + 1) & 1, q0 + 64);
     const unsigned sb = lds0 + (unsigned)(j & 1) * STAGE;
     unsigned aq[KSTEPS], ado[KSTEPS], atq[DO_DK ? KSTEPS : 1], atdo[DO_DV ? KSTEPS : 1];
@@ -513,12 +526,19 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
       };
       using H0 = std::integral_constant<int, 0>;
       using H1 = std::integral_constant<int, 1>;
+      KV_STAMP(2);  // [2] copy requests of the next tile + fragment addresses
       sp(H0{}, [&](auto) {});
+      KV_STAMP(3);  // [3] segment A: S, dP of half 0
       sp(H1{}, [&](auto I) { elem(H0{}, I); });
       packs(H0{});
+      KV_STAMP(4);  // [4] segment B
       dvdk(H0{}, [&](auto I) { elem(H1{}, I); });
       packs(H1{});
+      KV_STAMP(5);  // [5] segment C
       dvdk(H1{}, [&](auto) {});
+#ifdef MH_KV_TIMING
+      tacc[6] += 1;  // full tiles
+#endif
       return;
     }
     static_for<2>([&](auto HALF) {
@@ -604,8 +624,18 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
   const int j_full_end = keys_full ? max(n_diag, ntiles - n_tail) : n_diag;
   stage(0, q_begin);
   for (int j = 0; j < n_diag; ++j) tile(j, std::true_type{});
+#ifdef MH_KV_TIMING
+  if constexpr (MODE == 3) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#endif
   for (int j = n_diag; j < j_full_end; ++j) tile(j, std::false_type{});
   for (int j = max(n_diag, j_full_end); j < ntiles; ++j) tile(j, std::true_type{});
+#ifdef MH_KV_TIMING
+  if constexpr (MODE == 3) {
+    KV_STAMP(7);  // [7] last full tile's segment D + trailing edge tiles (not meaningful)
+    if (a.dbg && lane == 0)
+      for (int i = 0; i < 8; ++i) a.dbg[((int64_t)blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
+  }
+#endif
 
   if constexpr (ASM) {
 #pragma unroll
@@ -614,16 +644,9 @@ __global__ __launch_bounds__(256, MODE == 3 ? 1 : 2) void attn_bwd2_kv_k(Bwd2Arg
   if (kvrow < S) {
     const bool valid = kvrow < len;
     auto store_rows = [&](auto& acc, uint16_t* outp) {
-#pragma unroll
-      for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = 32 * i + 8 * g + 4 * hi;
-          uint2 w = make_uint2(0, 0);
-          if (valid)
-            w = make_uint2(pack2<DT>(acc[i][4 * g + 0], acc[i][4 * g + 1]), pack2<DT>(acc[i][4 * g + 2], acc[i][4 * g + 3]));
-          *(uint2*)(outp + d) = w;
-        }
+      auto val = [&](int i, int r) { return acc[i][r]; };
+      if (a.wide) store_row_wide<DT, DBLK>(outp, hi, valid, val);
+      else store_row_narrow<DT, DBLK>(outp, hi, valid, val);
     };
     if constexpr (DO_DV) store_rows(accv, outv);
     if constexpr (DO_DK) {
@@ -669,6 +692,10 @@ int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
 }  // namespace mhattn
 
 extern "C" void mh_attn_bwd_fused_kv(int on) { mhattn::g_attn_bwd_fused_kv = on ? 1 : 0; }
+#ifdef MH_KV_TIMING
+static unsigned long long* g_kv_timing_dbg = nullptr;
+extern "C" void mh_kv_timing_buffer(void* p) { g_kv_timing_dbg = (unsigned long long*)p; }
+#endif
 
 extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                             int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq,
@@ -691,6 +718,10 @@ extern "C" int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t l
   a.scale_log2 = a.scale * 1.4426950408889634f;
   a.inv_scale = sqrtf((float)D);
   a.rope = (const float2*)rope_cos_sin;
+  a.wide = ((lddq & 7) == 0) && ((lddk & 7) == 0) && ((lddv & 7) == 0) && aligned16(dq) && aligned16(dk) && aligned16(dv) && g_attn_wide_stores;
+#ifdef MH_KV_TIMING
+  a.dbg = g_kv_timing_dbg;
+#endif
   hipStream_t st = as_stream(stream);
 #define GO(DT_, D_, C_) return launch_bwd2<DT_, D_, C_>(a, st)
   if (dt == MH_BF16) {

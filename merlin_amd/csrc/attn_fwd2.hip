@@ -22,6 +22,7 @@ struct Fwd2Args {
   int64_t ldq, ldk, ldv, ldo;
   int B, S, H, S_pad;
   float scale_log2;
+  int wide;  // output rows are 16-byte aligned: the epilogue stores 16 bytes per lane (attn_tiles.h, store_row_wide)
 };
 
 template <int N>
@@ -244,14 +245,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_k(Fwd2Args a) {
   const float inv = (valid && l_tot > 0.f) ? 1.0f / l_tot : 0.f;
   if (qrow < S) {
     uint16_t* op = a.o + ((int64_t)b * S + qrow) * a.ldo + (int64_t)h * D;
-#pragma unroll
-    for (int i = 0; i < DBLK; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * i + 8 * g + 4 * hi;
-        *(uint2*)(op + d) = make_uint2(pack2<DT>(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv),
-                                       pack2<DT>(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv));
-      }
+    auto val = [&](int i, int r) { return o[i][r] * inv; };
+    if (a.wide) store_row_wide<DT, DBLK>(op, hi, true, val);  // 16-byte stores (T21); rows past `len` are written as zeros (inv = 0)
+    else store_row_narrow<DT, DBLK>(op, hi, true, val);
     if (hi == 0)
       a.lse[((int64_t)b * a.H + h) * a.S_pad + qrow] = (valid && l_tot > 0.f) ? (m_run + log2f(l_tot)) * 0.6931471805599453f : 0.f;
   }
@@ -277,8 +273,10 @@ int launch_attn_fwd_pingpong(const void* q, int64_t ldq, const void* k, int64_t 
                          const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st);  // attn_fwd3.hip
 int launch_attn_fwd_wave64(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
                            const int32_t* seqlens, int B, int S, int H, int causal, int dt, hipStream_t st);  // attn_fwd4.hip
+int g_attn_wide_stores = 1;   // A/B switch (mh_attn_wide_stores): 16-byte epilogue stores in the forward / backward kernels
 int g_attn_fwd_pingpong = 0;  // D = 128 forward form: 0 = attn_fwd2 (default), 1 = attn_fwd3 (ping-pong), 2 = attn_fwd4 (one wave per SIMD, 64 rows per wave)
 }  // namespace mhattn
+extern "C" void mh_attn_wide_stores(int on) { mhattn::g_attn_wide_stores = on ? 1 : 0; }
 extern "C" void mh_attn_fwd_pingpong(int on) { mhattn::g_attn_fwd_pingpong = (on == 2) ? 2 : (on ? 1 : 0); }
 
 extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
@@ -297,6 +295,7 @@ extern "C" int mh_attn_fwd2(const void* q, int64_t ldq, const void* k, int64_t l
   a.lse = lse; a.seqlens = seqlens; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.S = S; a.H = H; a.S_pad = (S + 63) / 64 * 64;
   a.scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  a.wide = ((ldo & 7) == 0) && aligned16(o) && g_attn_wide_stores;
   hipStream_t st = as_stream(stream);
 #define GO(DT_, D_, C_) return launch_fwd2<DT_, D_, C_>(a, st)
   if (dt == MH_BF16) {

@@ -221,4 +221,39 @@ __device__ __forceinline__ void stage_rows_buf(const RowSrc<D>& src, int r0, uns
   }
 }
 
+// ---- row-per-lane epilogue stores, widened (cdna guide T21) --------------------------------------------------------------------------
+// After a 32x32 MFMA chain a lane (row l31, half hi) holds, per accumulator block i and group g, the 4 channels 32 i + 8 g + 4 hi .. + 3 of
+// its row: the natural store is DBLK * 4 stores of 8 bytes.  One v_permlane32_swap per dword exchanges the upper half-wave's group g with
+// the lower half-wave's group g + 1, after which the lower lane holds channels 8 g .. 8 g + 7 and the upper lane 8 (g + 1) .. 8 (g + 1) + 7
+// of the row: DBLK * 2 stores of 16 bytes, same bytes, same addresses, half the store instructions (the epilogues are store-ISSUE
+// bound: MI355X_MICROARCH "attention epilogue store tail").  `rowp` = this lane's row (16-byte aligned, checked by the launchers through
+// `wide`); v(i, r) = the fp32 value of accumulator block i, register r, after whatever the caller applies; !valid rows are written as zeros.
+template <int DT, int DBLK, typename F>
+__device__ __forceinline__ void store_row_wide(uint16_t* rowp, int hi, bool valid, F&& v) {
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int gp = 0; gp < 4; gp += 2) {
+      uint32_t ax = 0, ay = 0, bx = 0, by = 0;
+      if (valid) {
+        ax = pack2<DT>(v(i, 4 * gp + 0), v(i, 4 * gp + 1)); ay = pack2<DT>(v(i, 4 * gp + 2), v(i, 4 * gp + 3));
+        bx = pack2<DT>(v(i, 4 * gp + 4), v(i, 4 * gp + 5)); by = pack2<DT>(v(i, 4 * gp + 6), v(i, 4 * gp + 7));
+      }
+      const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);  // (validity is a property of the ROW: both half-waves agree)
+      const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      *(uint4*)(rowp + 32 * i + 8 * gp + 8 * hi) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+    }
+}
+template <int DT, int DBLK, typename F>
+__device__ __forceinline__ void store_row_narrow(uint16_t* rowp, int hi, bool valid, F&& v) {
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 w = make_uint2(0, 0);
+      if (valid) w = make_uint2(pack2<DT>(v(i, 4 * g + 0), v(i, 4 * g + 1)), pack2<DT>(v(i, 4 * g + 2), v(i, 4 * g + 3)));
+      *(uint2*)(rowp + 32 * i + 8 * g + 4 * hi) = w;
+    }
+}
+
 }  // namespace mhattn

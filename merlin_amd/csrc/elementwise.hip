@@ -407,6 +407,25 @@ extern "C" int mh_clip_scale(const float* sumsq, float gscale, float max_norm, f
   hipLaunchKernelGGL(clip_scale_k, dim3(1), dim3(1), 0, as_stream(stream), sumsq, gscale, max_norm, out2);
   MH_LAUNCH_CHECK();
 }
+namespace {
+// flag |= 1 when any 16-bit element has a non-zero magnitude (bit pattern & 0x7fff: -0 is zero, NaN / Inf / denormals are NOT) - an EXACT test,
+// unlike a sum of squares (fp32 squares of |g| < ~1e-23 flush to zero)
+__global__ __launch_bounds__(256) void any_nonzero_k(const uint16_t* __restrict__ g, int64_t n, int* __restrict__ flag) {
+  const int64_t n8 = n >> 3;
+  unsigned acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = ((const uint4*)g)[i];
+    acc |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 7)) acc |= g[(n8 << 3) + threadIdx.x] & 0x7fffu;
+  if (__any(acc != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace
+extern "C" int mh_any_nonzero(const void* g, int64_t n, int* flag, void* stream) {
+  if (!g || !flag || n <= 0 || ((uintptr_t)g & 15u)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(any_nonzero_k, dim3(grid_for(n >> 3)), dim3(256), 0, as_stream(stream), (const uint16_t*)g, n, flag);
+  MH_LAUNCH_CHECK();
+}
 extern "C" int mh_sumsq(const void* g, int64_t n, float* out, int dt, void* stream) {
   if (!g || !out || n <= 0) return MH_ERR_ARG;
   DISPATCH16(dt, sumsq_k, grid_for(n), (const uint16_t*)g, n, out);

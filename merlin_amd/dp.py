@@ -76,22 +76,26 @@ class GradSync:
                 else:
                     p.grad.zero_()
         self._reduced = False
+        self._known_zero = True  # (settles the next backward's question without a pass over the arena)
 
     def _grads_all_zero(self) -> bool:
-        """True when the whole gradient arena holds zeros (one reduction + a host read: only taken on the rare path below)."""
+        """True when the whole gradient arena holds zeros.  EXACT (an OR over the bit patterns, mh_any_nonzero: a sum of squares flushes
+        |g| < ~1e-23 - representable in bf16 - to zero and NaNs need care); one pass over the arena + a host read, only taken when nothing
+        cheaper settles the question (_on_begin)."""
         g = self.engine.arena.gflat
         if g is None:
             return True
-        if g.is_cuda:
+        if g.is_cuda and g.element_size() == 2:
             from . import ops as O
 
-            out = torch.zeros(1, dtype=torch.float32, device=g.device)
-            O.sumsq(g, out)
-            return float(out.item()) == 0.0  # (NaN / Inf compare unequal: not zero)
-        return not bool(torch.count_nonzero(g))
+            flag = torch.zeros(1, dtype=torch.int32, device=g.device)
+            O.any_nonzero(g, flag)
+            return int(flag.item()) == 0
+        return not bool(torch.count_nonzero(g.view(torch.int16) & 0x7FFF)) if g.element_size() == 2 else not bool(torch.count_nonzero(g))
 
     def _on_begin(self, fresh: bool):
-        if fresh:
+        known_zero, self._known_zero = getattr(self, "_known_zero", False), False
+        if fresh or known_zero:
             self._reduced = False
         elif self._reduced and self.active:
             # Attached gradients that were already all-reduced.  Accumulating onto them is only sound when they hold ZEROS

@@ -1056,6 +1056,11 @@ def sumsq_det(g, partial, out):
     L.check(L.lib().mh_sumsq_det(p(g), i64(g.numel()), p(partial), p(out), i32(dt_of(g)), _stream()), "mh_sumsq_det")
 
 
+def any_nonzero(g, flag):
+    """flag (int32[1], zeroed by the caller) |= 1 when any 16-bit element of g is non-zero (exact, on the bit patterns)."""
+    L.check(L.lib().mh_any_nonzero(p(g), i64(g.numel()), p(flag), _stream()), "mh_any_nonzero")
+
+
 def sumsq(g, out):
     L.check(L.lib().mh_sumsq(p(g), i64(g.numel()), p(out), i32(dt_of(g)), _stream()), "mh_sumsq")
 

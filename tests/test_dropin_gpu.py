@@ -182,10 +182,26 @@ def test_released_geometry_448px_conv_stride2_vs_reference_golden(dtype):
         ref = g[f"grad/{k}/strided"].astype(np.float64)
         cos = float(samp @ ref / max(1e-30, np.linalg.norm(samp) * np.linalg.norm(ref)))
         ratio = float(f.double().norm()) / float(g[key])
-        cmin, rtol = (0.999, 0.01) if dtype == torch.float16 else ((0.80 if k == "lm_head.weight" else 0.99), 0.05)
+        # (bf16: lm_head's 512-element strided SAMPLE is noise - non-label vocabulary rows, see test_medium_backward_grad_norms_vs_reference_golden -
+        #  its norm is pinned here and the WHOLE tensor is held against the CPU oracle below)
+        cmin, rtol = (0.999, 0.01) if dtype == torch.float16 else ((-1.0 if k == "lm_head.weight" else 0.99), 0.05)
         if cos < cmin or abs(ratio - 1) > rtol:
             bad.append((k, cos, ratio))
     assert not bad, bad[:8]
+    # lm_head.weight's gradient, whole tensor, against the oracle's fp32 autograd on the same weights and batch (only that leaf requires grad)
+    from oracle import ref_cpu as R
+
+    gh = dict(model.named_parameters())["lm_head.weight"].grad.float().cpu()
+    P = R.make_params(cfg, seed=0)
+    P["lm_head.weight"].requires_grad_(True)
+    loss_ref, _ = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    gr = P["lm_head.weight"].grad
+    assert abs(float(gr.double().norm()) / float(g["grad/lm_head.weight/norm"]) - 1) < 1e-4  # the oracle's gradient IS the reference's
+    cos = float((gh.double() * gr.double()).sum() / (gh.double().norm() * gr.double().norm()))
+    ratio = float(gh.double().norm() / gr.double().norm())
+    print(f"[released geometry lm_head.weight grad {dtype}] whole-tensor cosine vs oracle {cos:.5f} norm ratio {ratio:.4f}; logits rel err {err:.3e}")
+    assert cos > (0.9995 if dtype == torch.float16 else 0.97) and abs(ratio - 1) < (0.01 if dtype == torch.float16 else 0.05), (cos, ratio)
 
 
 def test_packers_collator_and_image_preprocessing_feed_the_hip_forward():

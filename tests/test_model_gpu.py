@@ -2,8 +2,8 @@
   (a) golden vectors captured from the REAL reference (tests/golden/*.npz, oracle/make_golden.py) and
   (b) the CPU oracle (oracle/ref_cpu.py) run on the same generated weights for gradients.
 
-Tolerances (stated, per dtype): logits  max|d| / max|ref|  <= 2e-3 (fp16) / 1.5e-2 (bf16) on the tiny
-and medium models; loss rel-err <= 1e-3 / 5e-3; every parameter-gradient tensor: cosine >= 0.999
+Tolerances (stated, per dtype): logits  max|d| / max|ref|  <= 1e-3 (fp16: BASELINE.json's "within 1e-3 rel fp16", asserted on the
+tiny, medium and released-geometry models in the DEFAULT configuration = fp32 residual streams) / 1.5e-2 (bf16); loss rel-err <= 1e-3 / 5e-3; every parameter-gradient tensor: cosine >= 0.999
 (fp16) / 0.995 (bf16) and norm ratio within 1% / 3%.  BASELINE.json's "1e-3 rel fp16" is the fp16 row.
 """
 import os
@@ -15,10 +15,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-# fp16 = BASELINE.json's "within 1e-3 rel fp16" row: asserted at 1e-3 on the tiny fixtures (measured 7.6e-4 .. 9.3e-4, tools/measure_parity.py);
-# at real widths 16-bit storage alone costs more (medium 1.5e-3, released geometry 1.2e-3): those are asserted at 2e-3 here and at
-# 1e-3 in the fp32-store parity mode (tests/test_parity_mode_gpu.py)
-TOL = {torch.float16: dict(logits=2e-3, logits_tiny=1e-3, loss=1e-3, cos=0.999, norm=0.01),
+# fp16 = BASELINE.json's "within 1e-3 rel fp16" row: asserted at 1e-3 on the tiny fixtures, the medium model (real widths; measured 8.5e-4,
+# profiles/r04_parity_floor.txt) and the released geometry in the default configuration (fp32 residual streams).  With 16-bit streams
+# (engine.fp32_residual = False, the reference's own bf16-style storage) real widths cost more (medium 1.5e-3, released 1.2e-3): `logits_16bit_stream`.
+# Full 7B depth sits on the measured 16-bit-operand floor (tests/test_parity_floor_gpu.py) and at 1e-4 in the fp32-store parity mode.
+TOL = {torch.float16: dict(logits=1e-3, logits_tiny=1e-3, logits_16bit_stream=2e-3, loss=1e-3, cos=0.999, norm=0.01),
        torch.bfloat16: dict(logits=1.5e-2, loss=5e-3, cos=0.995, norm=0.03)}
 
 

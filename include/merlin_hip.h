@@ -258,7 +258,19 @@ void mh_attn_fwd_pingpong(int on);
 int mh_attn_bwd2(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                  const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
                  void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt, void* stream);
-/* dK and dV from one kernel (scores and dP computed once per tile; default) or from two (0): A/B switch. */
+/* The same backward in its FIVE-product form (D = 128, causal, S % 128 == 0, seqlens == NULL; any other case runs exactly mh_attn_bwd2): the
+ * dK|dV kernel writes the unscaled dS = P o (dP - delta) it computes anyway (16-bit, causal half only) into `ds_ws`
+ * (mh_attn_bwd_spill_bytes(B, S, H) bytes, scratch: may be shared by all layers of a step) and dQ = dS K is a one-product pass over it -
+ * no second evaluation of the scores, dP and the exponentials (flash-attention's backward executes 7 products for 5; the chip is power-capped,
+ * so executed work is what a kernel is billed for: profiles/r05_attn_bwd_spill.txt).  dK, dV are bit-identical to mh_attn_bwd2's, dQ agrees to
+ * rounding (P comes from the dK|dV kernel's exp2(s * c) with the accumulator started at -lse / scale instead of exp2(fma(s, c, -lse * log2e))). */
+int64_t mh_attn_bwd_spill_bytes(int B, int S, int H);
+int mh_attn_bwd2_spill(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
+                       const void* dout, int64_t lddo, const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                       void* dv, int64_t lddv, const int32_t* seqlens, int B, int S, int H, int D, int causal, const float* rope_cos_sin, int dt,
+                       void* ds_ws, void* stream);
+/* dK and dV at D = 128: 2 (default) = attn_bwd3_kv_k (one kernel; register-staged tile copies, three LDS stages, one barrier in the middle
+ * of a tile), 1 = attn_bwd2_kv_k<MODE 3> (one kernel, LDS-DMA copies: rounds 2-4), 0 = two kernels.  A/B switch, bit-identical results. */
 void mh_attn_bwd_fused_kv(int on);
 /* The row-per-lane epilogues of the attention kernels (o; dq, dk, dv) write 16 bytes per lane after a half-wave exchange (default, needs
  * 16-byte aligned rows: ld % 8 == 0) instead of 8 (0): A/B switch, bit-identical results (profiles/r05_attn_wide_stores.txt).

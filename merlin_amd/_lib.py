@@ -46,8 +46,10 @@ def lib() -> C.CDLL:
             _lib.mh_attn_bwd_ws_elems.restype = C.c_int64
         if os.environ.get("MH_GEMM_PERSISTENT") == "0":  # A/B switches for benchmarks
             _lib.mh_gemm_persistent(C.c_int(0))
-        if os.environ.get("MH_ATTN_BWD_FUSED_KV") == "0":
-            _lib.mh_attn_bwd_fused_kv(C.c_int(0))
+        if os.environ.get("MH_ATTN_BWD_FUSED_KV"):  # 0: dK, dV from two kernels; 1: attn_bwd2_kv_k<MODE 3>; 2: attn_bwd3_kv_k (default)
+            _lib.mh_attn_bwd_fused_kv(C.c_int(int(os.environ["MH_ATTN_BWD_FUSED_KV"])))
+        if os.environ.get("MH_ATTN_WIDE_STORES"):
+            _lib.mh_attn_wide_stores(C.c_int(int(os.environ["MH_ATTN_WIDE_STORES"])))
         if os.environ.get("MH_W4_MASK"):  # layouts the auto selection gives to the 4-wave GEMM (bit 0 TN, 1 NN, 2 NT)
             _lib.mh_gemm_w4_policy(C.c_int(int(os.environ["MH_W4_MASK"])))
         if os.environ.get("MH_GEMM_GM"):

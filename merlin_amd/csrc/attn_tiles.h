@@ -84,6 +84,16 @@ __device__ __forceinline__ void tr_frag_offsets(int lane, unsigned (&off)[D / 16
     }
 }
 
+// (one entry of the table above for a run-time d-block i: a table indexed by a run-time value would live in scratch memory)
+template <int D>
+__device__ __forceinline__ unsigned tr_frag_offset_one(int lane, int i, int rr) {
+  const int G = lane >> 4, hi = G >> 1, db = G & 1;
+  const int y = (lane & 15) >> 2, x = (lane & 3) >> 1, z = lane & 1;
+  const int row = 8 * rr + 4 * hi + y;
+  const int chunk = (4 * i + 2 * db + x) ^ TileSwz<D>::f(row);
+  return (unsigned)((4 * hi + y) * (D * 2) + (chunk << 4) + 8 * z);
+}
+
 // global_load_lds of one [ROWS][D] row-major tile: gbase points at (row 0, col 0) of the tile for this (b,h);
 // row r of the tile is at gbase + min(r0 + r, rmax) * ld.  256 threads, wave-uniform LDS destination.
 // Tiles that lie wholly inside the sequence (all but the last one) need no clamp: their addresses are a wave-uniform tile base

@@ -833,13 +833,49 @@ def _delta_ws(B, H, S_pad, device):
     return ws
 
 
-def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None, rope=None):
-    """Backward without re-layout passes or workspace (transpose-read kernels).  rope = (cos, sin) table: dq and dk leave
-    the kernels already rotated back (inverse RoPE fused into the epilogues: gradients w.r.t. the UN-rotated q, k)."""
+_spill_cache = {}
+ATTN_BWD_SPILL = os.environ.get("MH_ATTN_BWD_SPILL", "1") != "0"  # five-product backward (dS spilled by the dK|dV kernel) where it applies
+
+
+def attn_bwd_spill(on: bool):
+    """A/B switch: the causal D = 128 backward runs in its five-product form (dS written by the dK|dV kernel, dQ = dS K as a one-product pass)."""
+    global ATTN_BWD_SPILL
+    ATTN_BWD_SPILL = bool(on)
+
+
+def _spill_ws(B, S, H, device):
+    """dS scratch of the five-product attention backward (4.4 GB at cfg 3, 8.7 GB at cfg 5): ONE grow-only buffer per (device, stream), shared
+    by every layer (launches on one stream are ordered)."""
+    lib = L.lib()
+    lib.mh_attn_bwd_spill_bytes.restype = C.c_int64
+    need = int(lib.mh_attn_bwd_spill_bytes(i32(B), i32(S), i32(H)))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _spill_cache.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if len(_spill_cache) > 4:
+            _spill_cache.clear()
+        ws = _spill_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
+def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk=None, dv=None, rope=None, spill=None):
+    """Backward without re-layout passes (transpose-read kernels).  rope = (cos, sin) table: dq and dk leave the kernels already rotated
+    back (inverse RoPE fused into the epilogues: gradients w.r.t. the UN-rotated q, k).  spill (None = ATTN_BWD_SPILL): the causal D = 128
+    case with S % 128 == 0 and no ragged lengths runs as FIVE products - the dK|dV kernel spills dS into a scratch buffer, dQ = dS K."""
     dq = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dk is None else dk
     dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
     delta = _delta_ws(B, H, round_up(S, 64), q.device)  # [delta | lse*log2e]
+    use_spill = ATTN_BWD_SPILL if spill is None else spill
+    ws = _spill_ws(B, S, H, q.device) if (use_spill and causal and D == 128 and S % 128 == 0 and seqlens is None) else None
+    if ws is not None:
+        L.check(L.lib().mh_attn_bwd2_spill(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
+                                           p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
+                                           p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), p(rope),
+                                           i32(dt_of(q)), p(ws), _stream()), "mh_attn_bwd2_spill")
+        return dq, dk, dv
     L.check(L.lib().mh_attn_bwd2(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
                                  p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
                                  p(dv), i64(dv.stride(0)), p(seqlens), i32(B), i32(S), i32(H), i32(D), i32(int(causal)), p(rope),

@@ -24,6 +24,9 @@ def main():
     B, S = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 4096)
     H, D = 32, 128
     lib = C.CDLL(os.path.join(HERE, "attn_bwd2_timing.so"))
+    form = int(os.environ.get("KV_FORM", "2"))  # 1: attn_bwd2_kv_k<MODE 3> (LDS-DMA copies), 2: attn_bwd3_kv_k (register-staged)
+    lib.mh_attn_bwd_fused_kv(C.c_int(form))
+    print("kernel form:", form)
     g = torch.Generator(device="cuda").manual_seed(S + B)
     qkv = torch.randn(B * S, 3 * H * D, generator=g, device="cuda").to(torch.bfloat16)
     q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
@@ -50,9 +53,10 @@ def main():
     # product library on the same inputs: the instrumented build must agree bit for bit
     dq2, dk2, dv2 = O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True)
     print("bit-identical to the product kernels:", bool(torch.equal(dk, dk2) and torch.equal(dv, dv2) and torch.equal(dq, dq2)))
-    names = ["D (closing seg.)", "vmcnt(0)+barrier", "copies+addresses", "A: S,dP h0", "B: S,dP h1 | elem h0", "C: dV,dK h0 | elem h1"]
+    names = ["D (closing seg.)", "vmcnt(0)+barrier" if form == 1 else "barrier (mid-tile)", "copies+addresses" if form == 1 else "-", "A: S,dP h0",
+             "B: S,dP h1 | elem h0", "C: dV,dK h0 | elem h1"]
     ntile = t[:, :, 6]
-    for lo, hi in ((60, 65), (30, 34), (8, 12), (1, 4)):
+    for lo, hi in ((57, 65), (27, 34), (6, 12), (1, 4)):
         sel = (ntile[:, 0] >= lo) & (ntile[:, 0] < hi)
         if not bool(sel.any()):
             continue

@@ -177,7 +177,10 @@ def parse_args(argv=None):
     ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the N>1 code path (RCCL process group of one rank, GradSync on its "
                     "communication stream, per-rank gathers, headroom check) on the one GPU - a hardware check of the multi-GPU plumbing")
     ap.add_argument("--min-free-gb", type=float, default=10.0, help="N>1: if less HBM than this stays free next to RCCL's buffers after the "
-                    "first warm-up step, every rank switches to layer recompute (reported as `recompute_fallback`)")
+                    "first warm-up step, every rank lowers its resident-activation footprint: engine.mem_level 1 (normed GEMM operands re-derived in "
+                    "backward, -20 GB), 2 (+ SwiGLU outputs of 16 layers recomputed, -31 GB), then full layer recompute (`recompute_fallback`)")
+    ap.add_argument("--mem-level", type=int, default=0, choices=[0, 1, 2], help="engine.mem_level to start from (0 = keep every activation resident)")
+    ap.add_argument("--no-cfg5-extra", action="store_true", help="skip the cfg-5 (S=8192 interleave, fp8 weight path) row of the N=1 line's `extras`")
     return ap.parse_args(argv)
 
 
@@ -353,6 +356,7 @@ def main(argv=None):
         model = build_synthetic_model(LLAMA_7B, VIT_L_336, projector="mlp", dtype=torch.bfloat16, device=dev, seed=0)
         eng = model.engine
         eng.save_activations = not args.recompute
+        eng.mem_level = args.mem_level
         eng.fp32_residual = not args.residual_16bit
         if args.fp8_forward:
             assert args.fwd_only, "--fp8-forward is forward-only"
@@ -423,15 +427,24 @@ def main(argv=None):
             print(f"[bench] warm-up step {wi}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
         if wi == 0 and dp and not dry and not args.fwd_only and eng.save_activations:
             # RCCL has allocated its channels / staging buffers by now (the first all-reduces ran): with activations resident the
-            # step peaks at ~251 of 288 GB on one GPU - if less than --min-free-gb stays free on ANY rank, all ranks recompute
+            # step peaks at ~255 of 288 GB on one GPU.  If less than --min-free-gb stays free on ANY rank, all ranks step down together: first
+            # engine.mem_level 1 / 2 (activations the backward re-derives: a slope of ~0.5 % / ~1 % step time), full layer recompute last.
             dev_sync()
             free_b, total_b = torch.cuda.mem_get_info(dev)
             headroom = (free_b + torch.cuda.memory_reserved(dev) - torch.cuda.max_memory_allocated(dev)) / 1e9
             hbm_info = {"hbm_total_gb": round(total_b / 1e9, 1), "hbm_headroom_gb_after_first_step": round(all_min(headroom), 1)}
-            if hbm_info["hbm_headroom_gb_after_first_step"] < args.min_free_gb:
-                eng.save_activations = False
-                recompute_fallback = True
+            short = args.min_free_gb - hbm_info["hbm_headroom_gb_after_first_step"]
+            scale = n_tok / 32768.0  # (savings quoted at cfg 3's 32 768 tokens per GPU)
+            if short > 0:
+                if eng.mem_level < 1 and short <= 19.8 * scale:
+                    eng.mem_level = 1
+                elif eng.mem_level < 2 and short <= 31.3 * scale:
+                    eng.mem_level = 2
+                else:
+                    eng.save_activations = False
+                    recompute_fallback = True
                 torch.cuda.empty_cache()
+            hbm_info["mem_level"] = eng.mem_level
     dev_sync()
     if dp:
         dist.barrier()
@@ -513,6 +526,8 @@ def main(argv=None):
                    "loss_first_warmup_step": (round(float(loss_first), 4) if loss_first is not None else None)},
         "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
         "peak_hbm_gb": round(peak_gb, 1),
+        "hbm_headroom_gb": (None if dry else round(torch.cuda.get_device_properties(dev).total_memory / 1e9 - peak_gb, 1)),
+        "mem_level": (None if dry else eng.mem_level),
         "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "bf16 MFMA GEMM kernels (gemm_nt_256 / gemm_w4 / gemm_nt_128, all launches)"),
                      "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
@@ -577,11 +592,23 @@ def main(argv=None):
                 dev_sync()
                 t_fw = (time.perf_counter() - tq) / 10
             f2 = algorithmic_flops_fwd(1, S2, 1)
+            # At S = 613 the step is HBM-bound, not MFMA-bound: the roof is the bytes a step has to stream - forward: every 16-bit weight
+            # once (14.09 GB); training step: weights twice (forward, dgrad) + 16-bit gradients written once + AdamW (read p, g, m, v; write p, m, v =
+            # 22 B per parameter) - against 8 TB/s
+            n_par = eng.arena.total
+            b_fwd, b_train = 2.0 * n_par, (2.0 * 2 + 2.0 + 22.0) * n_par
             line["extras"] = {"cfg2": {"workload": "single 336px image + 32-token caption (S=613), B=1", "train_ms_per_step": round(t_tr * 1e3, 2),
                                        "train_tokens_per_s": round(S2 / t_tr, 1), "forward_ms": round(t_fw * 1e3, 2),
-                                       "forward_tokens_per_s": round(S2 / t_fw, 1), "forward_mfma_roofline_frac": round(f2 / t_fw / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+                                       "forward_tokens_per_s": round(S2 / t_fw, 1), "forward_mfma_roofline_frac": round(f2 / t_fw / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                       "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                                                    "forward": {"algorithmic_gb": round(b_fwd / 1e9, 2), "achieved": round(b_fwd / t_fw / 1e9, 1),
+                                                                "frac": round(b_fwd / t_fw / 8e12, 4)},
+                                                    "train_step": {"algorithmic_gb": round(b_train / 1e9, 2), "achieved": round(b_train / t_tr / 1e9, 1),
+                                                                   "frac": round(b_train / t_tr / 8e12, 4)}}}}
         except Exception as e:
             line["extras"] = {"cfg2": f"failed: {e}"}
+        if not args.no_cfg5_extra:
+            line.setdefault("extras", {})["cfg5"] = cfg5_extra(model, eng, O, synth, to_dev, train_step, dev_sync, dev)
     if not args.no_cpu_baseline and world == 1 and not dry:  # (the reported CPU baseline belongs to the N = 1 line only)
         try:
             line["cpu_baseline"] = cpu_baseline()
@@ -590,6 +617,71 @@ def main(argv=None):
     os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dp:
         dist.destroy_process_group()
+
+
+def cfg5_extra(model, eng, O, synth, to_dev, train_step, dev_sync, dev, warm=2, steps=4):
+    """BASELINE configs[4] on the same model, driver-timed like the rest of the line: S = 8192 interleave (4 images + long text per document), B = 4
+    per GPU, every decoder Linear + lm_head on the scaled-fp8 MFMA (forward, dgrad, wgrad), bf16 elsewhere; a few training steps."""
+    import gc
+
+    try:
+        gc.collect()
+        torch.cuda.empty_cache()
+        b5 = synth.interleave_batch(B=4, S=8192, n_images=4, rank=0)
+        d5 = to_dev(b5)
+        n_tok5 = int(b5["attention_mask"].sum())
+        n_img5 = sum(int(im.shape[0]) for im in b5["images"])
+        model.fp8_training = True
+        torch.cuda.reset_peak_memory_stats(dev)
+        for _ in range(warm):
+            train_step(d5)
+        dev_sync()
+        O.profile_start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_step(d5)
+        dev_sync()
+        dt = (time.perf_counter() - t0) / steps
+        prof = O.profile_stop()
+        n8, work8, ms8 = prof.get("gemm_fp8", (0, 0.0, 1e-9))
+        n16, work16, ms16 = prof.get("gemm_nt", (0, 0.0, 1e-9))
+        fwd = algorithmic_flops_fwd(4, 8192, n_img5)
+        out = {"workload": "interleave (MMC4-style): B=4 x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path (decoder Linears + lm_head: "
+                           "forward, dgrad, wgrad), bf16 attention / norms / CLIP tower, 16-bit residual streams",
+               "ms_per_step": round(dt * 1e3, 2), "tokens_per_s": round(n_tok5 / dt, 1), "steps": steps, "warmup": warm,
+               "loss": round(float(loss.detach()), 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+               "useful_tflops": round(3 * fwd / dt / 1e12, 1), "parts_on_fp8": dict(getattr(eng, "last_fp8", {})),
+               "roofline": {"kernel": "scaled-fp8 MFMA GEMMs (gemm_w4_f8 / gemm_nt_256<F8>, all launches)", "bound": "mfma",
+                            "achieved": round(work8 / (ms8 * 1e-3) / 1e12, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(work8 / (ms8 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4), "launches": n8,
+                            "share_of_step": round(ms8 / steps / (dt * 1e3), 3), "traffic": None,
+                            "bf16_gemm_share_of_step": round(ms16 / steps / (dt * 1e3), 3)}}
+        t5 = cfg5_traffic()
+        if t5:
+            out["roofline"].update(t5)
+        return out
+    except Exception as e:  # never take the headline down
+        return f"failed: {type(e).__name__}: {e}"
+    finally:
+        model.fp8_training = False
+
+
+def cfg5_traffic():
+    """profiles/rNN_gemm_traffic_cfg5.json (tools/pmc_step_traffic.sh --config cfg5), quoted only when taken on this build's GEMM sources."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_traffic_cfg5.json")))
+    if not found:
+        return None
+    try:
+        with open(found[-1]) as f:
+            t = json.load(f)
+        if t.get("kernel_source_stamp") != kernel_source_stamp():
+            return {"traffic_unit": f"profiles/{os.path.basename(found[-1])} was taken on other kernel sources: not quoted"}
+        return {"traffic": round(t["traffic_bytes_per_launch"] / 1e9, 3), "traffic_over_algorithmic": round(t.get("traffic_over_algorithmic", 0), 2),
+                "traffic_unit": f"GB per fp8 GEMM kernel launch (L2<->fabric, PMC: profiles/{os.path.basename(found[-1])})"}
+    except Exception:
+        return None
 
 
 def sustained_mfma_tflops():

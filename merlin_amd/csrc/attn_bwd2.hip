@@ -691,7 +691,11 @@ __device__ __forceinline__ void bload64(u32x2_t& d, unsigned voff, const i32x4_t
 // can see and drain the LDS-DMA copies queued between them)
 template <int OFF>
 __device__ __forceinline__ void gload128(u32x4_t& d, const void* ptr) {
+#ifdef MH_SPILL_TEMPORAL
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");
+#else
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");  // (streamed once)
+#endif
 }
 template <int OFF>
 __device__ __forceinline__ void lds_write128(unsigned addr, const u32x4_t& v) {
@@ -895,7 +899,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd3_kv_k(Bwd2Args a) {
   };
   auto spill_store = [&](const char* unit, auto HF, auto KS, const u32x4_t& o) {
     constexpr int hf = decltype(HF)::value, ks = decltype(KS)::value;
+    // (written once, read once by another kernel: non-temporal, so that the stream does not evict the Q / dO tiles the 32 key blocks of a (batch, head) share in L2)
+#ifdef MH_SPILL_TEMPORAL
     *(u32x4_t*)(const_cast<char*>(unit) + ds_vo + (hf * 2 + ks) * 1024) = o;
+#else
+    __builtin_nontemporal_store(o, (u32x4_t*)(const_cast<char*>(unit) + ds_vo + (hf * 2 + ks) * 1024));
+#endif
   };
   auto spill = [&](const char* unit, auto HF, auto KS, const u32x4_t& d) {
     if constexpr (SPILL) spill_store(unit, HF, KS, spill_prep(d));

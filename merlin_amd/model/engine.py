@@ -66,6 +66,13 @@ class HipEngine:
         # 1.1x of the measured 16-bit-operand floor: tests/test_parity_floor_gpu.py) at +1.4 % step time.  False = 16-bit streams (the
         # reference's own bf16 training numerics).  The fp8 paths keep 16-bit streams.
         self.fp32_residual = True
+        # Resident-activation footprint (save_activations = True), a slope instead of the cliff to full layer recompute (bench.py picks the lowest
+        # level that leaves --min-free-gb of HBM next to RCCL's buffers): 0 = keep everything (251 GB at cfg 3, the fastest); 1 = do not keep the
+        # normed GEMM operands h1 / h2 of the decoder and tower layers - the backward re-derives them from the saved 16-bit layer inputs with the
+        # forward's norm kernels right before the weight gradients that read them (-19.8 GB for ~7 ms per step); 2 = additionally recompute
+        # act = silu(gate) * up from the saved gate|up tensor in the first `mem_act_layers` decoder layers (-0.72 GB and +0.45 ms per layer).
+        self.mem_level = 0
+        self.mem_act_layers = 16
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -248,7 +255,7 @@ class HipEngine:
             f1 = None
             a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
         y = O.gemm_nt(a, W.w2, bias=W.b2, resid=x2)
-        return y, ((h1, qkv, o, lse, x2, h2, f1, a) if keep else None)
+        return y, (((None if self.mem_level else h1), qkv, o, lse, x2, (None if self.mem_level else h2), f1, a) if keep else None)
 
     @staticmethod
     def _fc1_gelu(h2, W):
@@ -266,6 +273,9 @@ class HipEngine:
         if saved is None:
             _, saved = self._vit_layer_fwd(W, x, N, S, vc, keep=True)
         h1, qkv, o, lse, x2, h2, f1, a = saved
+        if h1 is None:  # mem_level >= 1: re-derived from the saved 16-bit layer inputs
+            h1 = O.layernorm_fwd(x, W.ln1w, W.ln1b, eps)
+            h2 = O.layernorm_fwd(x2, W.ln2w, W.ln2b, eps)
         T = x.shape[0]
         Tpad = _ru(T, 64)
         p = W.p
@@ -569,7 +579,15 @@ class HipEngine:
         h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
         gu, act = O.gemm_swiglu_fwd(h2, W.wgu)  # gate|up projection; SwiGLU in the same launch's epilogue
         y = O.gemm_nt(act, W.wd, resid=x2)
-        return y, ((h1, qkv, o, lse, x2, h2, gu, act, packed) if keep else None)
+        return y, (self._slim(W, (h1, qkv, o, lse, x2, h2, gu, act, packed)) if keep else None)
+
+    def _slim(self, W, saved):
+        """mem_level: drop what the backward can re-derive (see __init__)."""
+        if not self.mem_level:
+            return saved
+        h1, qkv, o, lse, x2, h2, gu, act, packed = saved
+        drop_act = self.mem_level >= 2 and int(W.p.split(".")[2]) < self.mem_act_layers
+        return (None, qkv, o, lse, x2, None, gu, None if drop_act else act, packed)
 
     def _llama_layer_fwd_r32(self, W, x32, B, S, lens, keep, kv_out=None, unpad=None, need_x16=True):
         """_llama_layer_fwd on the fp32 residual stream: x32 [T, d] is updated IN PLACE; returns (x16 = the 16-bit copy of the layer
@@ -584,7 +602,7 @@ class HipEngine:
         h2, x2_16 = O.norm_fwd_f32in(x32, W.ln2, eps, want_x16=keep)
         gu, act = O.gemm_swiglu_fwd(h2, W.wgu)
         O.gemm_nt(act, W.wd, out=x32, accum=True)         # x += act Wd^T
-        return x16, ((h1, qkv, o, lse, x2_16, h2, gu, act, packed) if keep else None)
+        return x16, (self._slim(W, (h1, qkv, o, lse, x2_16, h2, gu, act, packed)) if keep else None)
 
     def _vit_layer_fwd_r32(self, W, x32, N, S, vc, keep, need_x16=True):
         H = vc.num_attention_heads
@@ -603,7 +621,7 @@ class HipEngine:
             f1 = None
             a = O.gemm_nt(h2, W.w1, bias=W.b1, act="quick_gelu")
         O.gemm_nt(a, W.w2, bias=W.b2, out=x32, accum=True)
-        return x16, ((h1, qkv, o, lse, x2_16, h2, f1, a) if keep else None)
+        return x16, (((None if self.mem_level else h1), qkv, o, lse, x2_16, (None if self.mem_level else h2), f1, a) if keep else None)
 
     # ---- attention under a key-padding mask (llama_flash_attn_monkey_patch.py:87-102) ---------------------------------------------
     # Right-padded batches (the collator's, collator.py:29-34) only need per-sample lengths: the kernels skip keys >= lens[b] and
@@ -800,12 +818,16 @@ class HipEngine:
         train = self._trainable(p + "mlp.down_proj.weight")
         dgu = O.gemm_swiglu_bwd(dy, W.wd, gu)  # dact = dy Wd never leaves the kernel: SwiGLU backward in the epilogue
         if train:
+            if act is None:  # mem_level 2: not kept
+                act = O.swiglu_fwd(gu)
             self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
         del act
         dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
         if train:
+            if h2 is None:  # mem_level >= 1: the normed operand is re-derived from the saved 16-bit layer-half input
+                h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
             self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
-        del dgu, gu
+        del dgu, gu, h2
         dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
                             dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
         do = O.gemm_nt(dx2, W.wo, b_t=True)
@@ -814,7 +836,10 @@ class HipEngine:
         dqkv = self._attn_bwd(qkv, o, do, lse, B, S, H, D, lens, unpad, packed)
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
+            if h1 is None:
+                h1 = O.rmsnorm_fwd(x, W.ln1, eps)
             self._wgrad(dqkv, h1, A.gspan(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (3 * d, d)), fresh, Tpad)
+        del h1
         dx = O.rmsnorm_bwd(x, W.ln1, dh1, eps, dx=dx2, accumulate_dx=True,
                            dw_out=A.gview(p + "input_layernorm.weight") if train else None, dw_accumulate=acc)
         if train:

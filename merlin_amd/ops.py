@@ -1144,9 +1144,10 @@ def attn_fwd_pingpong(on):
     L.lib().mh_attn_fwd_pingpong(i32(int(on)))
 
 
-def attn_bwd_fused_kv(on: bool):
-    """A/B switch: dK and dV of the attention backward from one kernel (default) or two."""
-    L.lib().mh_attn_bwd_fused_kv(i32(int(on)))
+def attn_bwd_fused_kv(on):
+    """A/B switch for dK and dV of the D = 128 attention backward: True / 2 = attn_bwd3_kv_k (default: one kernel, register-staged copies,
+    continuous fragment stream), 1 = attn_bwd2_kv_k<MODE 3> (one kernel, LDS-DMA copies: rounds 2-4), False / 0 = two kernels."""
+    L.lib().mh_attn_bwd_fused_kv(i32(2 if on is True else int(on)))
 
 
 def gemm_raster_group(gm: int):

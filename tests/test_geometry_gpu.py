@@ -78,7 +78,15 @@ def test_attention_at_benchmark_sequence_lengths(dtype, B, S, H, D, causal, lens
         dq2, dk2, dv2 = O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=lt if lens else None)
     finally:
         O.attn_bwd_fused_kv(True)
-    assert torch.equal(dk2, dk) and torch.equal(dv2, dv) and torch.equal(dq2, dq)
+    # (dq: where the five-product form ran above - causal, S % 128 == 0, no lengths - the two-kernel form's dQ comes from other kernels and agrees to
+    #  rounding; everything else bit for bit)
+    assert torch.equal(dk2, dk) and torch.equal(dv2, dv)
+    if causal and D == 128 and S % 128 == 0 and not lens and O.ATTN_BWD_SPILL:
+        assert _relerr(dq2, dq.float()) < 2 * EPS[dtype]
+        dq3, dk3, dv3 = O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, spill=False)
+        assert torch.equal(dq3, dq2) and torch.equal(dk3, dk) and torch.equal(dv3, dv)
+    else:
+        assert torch.equal(dq2, dq)
 
 
 def _sample_tiles(M, N, n=6, t=96, seed=0):

@@ -203,6 +203,45 @@ def test_fp32_residual_stream_forward_backward_parity(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["tiny_2img", "tiny_padbatch"])
+def test_mem_level_rederived_activations_give_the_same_gradients(name, dtype):
+    """engine.mem_level 1 / 2 (bench.py's slope between 'everything resident' and full layer recompute): the normed GEMM operands h1 / h2 are
+    re-derived in backward from the saved 16-bit layer inputs, act = silu(gate) * up from the saved gate|up tensor.  With 16-bit residual
+    streams that is the forward's own arithmetic: gradients bit-identical to mem_level 0.  With fp32 streams (default) the forward normed the
+    fp32 stream and the backward norms its 16-bit copy - one rounding of the norm's INPUT apart: every gradient within cosine 0.9999."""
+    from oracle import cases as C
+
+    cfg, batch = C.get_case(name)
+    model = _build(cfg, dtype)
+    eng = model.engine
+    eng.save_activations = True
+    eng.mem_act_layers = 1
+    grads = {}
+    for r32 in (False, True):
+        for lvl in (0, 1, 2):
+            for p in model.parameters():
+                p.grad = None
+            eng.fp32_residual, eng.mem_level = r32, lvl
+            out = model(**_to_dev(batch))
+            out.loss.backward()
+            grads[(r32, lvl)] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    eng.mem_level = 0
+    assert all(torch.equal(grads[(False, 1)][k], g) for k, g in grads[(False, 0)].items()), "16-bit streams, mem_level 1"
+    # (mem_level 2: the 4-wave GEMM's fused SwiGLU gates the fp32 accumulators, the stand-alone kernel the rounded gate|up tensor - one rounding apart
+    #  at shapes that kernel takes)
+    for r32, lvl in ((False, 2), (True, 1), (True, 2)):
+        bad = []
+        for k, g in grads[(r32, 0)].items():
+            a, b = grads[(r32, lvl)][k].float().reshape(-1), g.float().reshape(-1)
+            if float(b.norm()) == 0.0:
+                continue
+            cos = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+            if cos < 0.9999:
+                bad.append((k, cos))
+        assert not bad, (r32, lvl, bad[:6])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_medium_backward_grad_norms_vs_reference_golden(dtype):
     """Gradient digests (norm + strided sample) of every parameter vs the reference's (medium golden).
     fp16: every sampled cosine >= 0.999 and norms within 1 % - the strict check of the backward maths.

@@ -262,7 +262,12 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     do_masked = do.clone()
     ref.backward(do.float().view(B, S, H, D))
     tol = 8 * EPS16[dtype]
+    # (default call first: where the five-product form applies - causal, D = 128, S % 128 == 0, no lengths - it is what runs)
+    dq1, dk1, dv1 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    assert relerr(dq1.view(B, S, H, D), q32.grad) < tol and relerr(dk1.view(B, S, H, D), k32.grad) < tol and relerr(dv1.view(B, S, H, D), v32.grad) < tol
+    ops.attn_bwd_spill(False)  # the bit-identity chain below compares seven-product kernels (restored at the end of the test)
     dq2, dk2, dv2 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    assert torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
     assert relerr(dv2.view(B, S, H, D), v32.grad) < tol, "dv"
     assert relerr(dk2.view(B, S, H, D), k32.grad) < tol, "dk"
     assert relerr(dq2.view(B, S, H, D), q32.grad) < tol, "dq"
@@ -277,6 +282,51 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, D, causal, lens):
     finally:
         ops.attn_bwd_fused_kv(True)
     assert torch.equal(dq4, dq2) and torch.equal(dk4, dk2) and torch.equal(dv4, dv2)
+    # ... and = the rounds 2-4 fused kernel (attn_bwd2_kv_k<MODE 3>, LDS-DMA tile copies): the default since round 5 is attn_bwd3_kv_k
+    # (register-staged copies, three LDS stages, one barrier in the middle of a tile, one continuous fragment stream)
+    try:
+        ops.attn_bwd_fused_kv(1)
+        dq5, dk5, dv5 = ops.attn_bwd2(q, k, v, o, do_masked, lse, B, S, H, D, causal, seqlens=lens_t if lens else None)
+    finally:
+        ops.attn_bwd_fused_kv(True)
+        ops.attn_bwd_spill(True)
+    assert torch.equal(dq5, dq2) and torch.equal(dk5, dk2) and torch.equal(dv5, dv2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H", [(1, 128, 1), (2, 256, 2), (1, 640, 3), (2, 1152, 2), (1, 2048, 2)])
+def test_attention_bwd_five_product_form(ops, dtype, B, S, H):
+    """The causal D = 128 backward with S % 128 == 0 and no ragged lengths in its FIVE-product form (ops.attn_bwd2(..., spill=True), the
+    default where it applies): the dK|dV kernel spills the unscaled dS it computes anyway, dQ = dS K is a one-product pass (attn_bwd3_dq_k).
+    dK, dV bit-identical to the seven-product form; dQ against the fp32 reference with the same bound; deterministic; the fused inverse RoPE
+    of dQ agrees with the seven-product form's; the dS scratch is shared between calls of different shapes."""
+    D = 128
+    qkv = rnd(B * S, 3 * H * D, dtype=dtype, scale=1.0, seed=S)
+    q, k, v = (qkv[:, i * H * D:(i + 1) * H * D] for i in range(3))
+    lens_t = torch.full((B,), S, dtype=torch.int32, device=dev())
+    o, lse = ops.attn_fwd2(q, k, v, B, S, H, D, True)
+    q32, k32, v32 = (t.float().reshape(B, S, H, D).clone().requires_grad_() for t in (q, k, v))
+    ref = _attn_ref(q32, k32, v32, True, lens_t.long())
+    do = rnd(B * S, H * D, dtype=dtype, seed=9)
+    ref.backward(do.float().view(B, S, H, D))
+    dq7, dk7, dv7 = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, spill=False)
+    dq5, dk5, dv5 = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, spill=True)
+    assert torch.equal(dk5, dk7) and torch.equal(dv5, dv7)
+    tol = 8 * EPS16[dtype]
+    e7, e5 = relerr(dq7.view(B, S, H, D), q32.grad), relerr(dq5.view(B, S, H, D), q32.grad)
+    assert e5 < tol and e5 < 1.1 * e7 + 1e-5, (e5, e7)
+    dq5b, dk5b, dv5b = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, spill=True)
+    assert torch.equal(dq5b, dq5) and torch.equal(dk5b, dk5) and torch.equal(dv5b, dv5)
+    tab = ops.rope_table(S, D, 10000.0, dev())
+    r7 = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, rope=tab, spill=False)
+    r5 = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, rope=tab, spill=True)
+    assert torch.equal(r5[1], r7[1]) and torch.equal(r5[2], r7[2])
+    assert relerr(r5[0], r7[0].float()) < 2 * EPS16[dtype]
+    # a ragged batch of the same shape falls back to the seven-product kernels (same entry point)
+    rag = torch.tensor([S] * (B - 1) + [S - 3], dtype=torch.int32, device=dev())
+    a = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=rag, spill=True)
+    b_ = ops.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, True, seqlens=rag, spill=False)
+    assert all(torch.equal(x, y) for x, y in zip(a, b_))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

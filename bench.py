@@ -180,6 +180,10 @@ def parse_args(argv=None):
                     "first warm-up step, every rank lowers its resident-activation footprint: engine.mem_level 1 (normed GEMM operands re-derived in "
                     "backward, -20 GB), 2 (+ SwiGLU outputs of 16 layers recomputed, -31 GB), then full layer recompute (`recompute_fallback`)")
     ap.add_argument("--mem-level", type=int, default=0, choices=[0, 1, 2], help="engine.mem_level to start from (0 = keep every activation resident)")
+    ap.add_argument("--emulate-comm", type=int, default=0, metavar="BLOCKS", help="N=1 only, measurement aid for the N>1 case no node is available for: "
+                    "as every gradient bucket becomes final, a side stream streams it twice through BLOCKS workgroups (tools/probes/hbm_probe.so: the "
+                    "CU and HBM footprint of a ring all-reduce's kernels - RCCL itself moves nothing in a group of one rank); the line reports the "
+                    "bytes and the time the compute stream waited at the end of backward")
     ap.add_argument("--no-cfg5-extra", action="store_true", help="skip the cfg-5 (S=8192 interleave, fp8 weight path) row of the N=1 line's `extras`")
     return ap.parse_args(argv)
 
@@ -337,6 +341,7 @@ def main(argv=None):
 
     O = None
     model = None
+    emu = None
     recompute_fallback = False
     hbm_info = {}
     if dry:
@@ -400,6 +405,39 @@ def main(argv=None):
         opt = FusedAdamW(eng, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
         it = [0]
         sync = GradSync(eng, force=args.force_dp) if dp else None
+
+        emu = None
+        if args.emulate_comm and not dp:
+            import ctypes
+
+            plib = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "hbm_probe.so"))
+            emu = {"stream": torch.cuda.Stream(device=dev), "sink": torch.zeros(1 << 16, dtype=torch.int32, device=dev), "bytes": 0, "wait": [], "n": 0}
+
+            def _emu_ready(names):
+                A = eng.arena
+                cur = torch.cuda.current_stream(dev)
+                if names is None:  # end of backward: the optimizer must see "reduced" gradients
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record(cur)
+                    cur.wait_stream(emu["stream"])
+                    b_.record(cur)
+                    emu["wait"].append((a_, b_))
+                    return
+                names = [n for n in names if A.params[n].requires_grad]
+                if not names:
+                    return
+                off, num = A.range_of(names)
+                buf = A.gflat[off: off + num]
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                emu["stream"].wait_event(ev)
+                for _ in range(2):
+                    plib.hbm_read(ctypes.c_void_p(buf.data_ptr()), ctypes.c_int64(buf.numel() * buf.element_size()), ctypes.c_void_p(emu["sink"].data_ptr()),
+                                  args.emulate_comm, 4, ctypes.c_void_p(emu["stream"].cuda_stream))
+                emu["bytes"] += 2 * buf.numel() * buf.element_size()
+                emu["n"] += 1
+
+            eng.on_grads_ready = _emu_ready
 
         def train_step(db):
             out = model(**db)
@@ -609,6 +647,13 @@ def main(argv=None):
             line["extras"] = {"cfg2": f"failed: {e}"}
         if not args.no_cfg5_extra:
             line.setdefault("extras", {})["cfg5"] = cfg5_extra(model, eng, O, synth, to_dev, train_step, dev_sync, dev)
+    if not dry and emu is not None:
+        ws = [a_.elapsed_time(b_) for a_, b_ in emu["wait"][-args.steps:]]
+        tot = args.warmup + args.steps
+        line["comm_emulation"] = {"blocks": args.emulate_comm, "gb_streamed_per_step": round(emu["bytes"] / tot / 1e9, 2), "launch_pairs_per_step": emu["n"] // tot,
+                                  "compute_stream_wait_ms_per_step": round(sum(ws) / max(1, len(ws)), 3),
+                                  "what": "every gradient bucket read twice by a side-stream kernel of BLOCKS workgroups while the backward runs (stand-in for a ring all-reduce's kernels)"}
+        eng.on_grads_ready = None
     if not args.no_cpu_baseline and world == 1 and not dry:  # (the reported CPU baseline belongs to the N = 1 line only)
         try:
             line["cpu_baseline"] = cpu_baseline()

@@ -130,7 +130,7 @@ def test_full_7b_cfg1_forward_parity_vs_reference_golden(dtype, stream):
     assert np.array_equal(g["input_ids"], batch["input_ids"].numpy())
     model = _build(cfg, dtype)
     # stream = "fp32": engine.fp32_residual - both towers' residual streams in fp32 with the PRODUCTION GEMM / attention / norm kernels
-    # (VERDICT r2 #4); what is left is the 16-bit rounding of the GEMM operands (measured: profiles/r03_parity.txt)
+    # (VERDICT r2 #4); what is left is the 16-bit rounding of the GEMM operands (measured: profiles/r03_skinny_gemm.txt, profiles/r04_parity_floor.txt)
     model.engine.fp32_residual = stream == "fp32"
     with torch.no_grad():
         out = model(**_to_dev(batch))

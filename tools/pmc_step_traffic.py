@@ -48,16 +48,22 @@ L = max(1, launches)
 import bench  # noqa: E402  (kernel_source_stamp, algorithmic byte model)
 
 
+CFG5 = os.environ.get("PMC_CONFIG", "cfg3") == "cfg5"  # cfg 5: the same 32 768 tokens per step (B 4 x S 8192), 16 images, decoder + head operands are 1-byte e4m3
+
+
 def algorithmic_bytes_per_step():
-    """A + B + C moved once per GEMM of one cfg-3 training step (SURVEY §8d shapes): what bench.py's `algorithmic_gb_per_launch` sums."""
+    """A + B + C moved once per GEMM of one cfg-3 training step (SURVEY §8d shapes): what bench.py's `algorithmic_gb_per_launch` sums.
+    PMC_CONFIG=cfg5: the fp8 step - decoder / lm_head operands are one byte per element (the quantised copies), outputs as in the bf16 step."""
     T, d, ff, V, L = 8 * 4096, 4096, 11008, 32064, 32
+    osz = 1.0 if CFG5 else 2.0
     def g(M, N, K, csize=2):
-        return 2.0 * (M * K + N * K) + csize * M * N
+        return osz * (M * K + N * K) + csize * M * N
     fwd = g(T, 3 * d, d) + g(T, d, d) + 2.0 * (T * d + 2 * ff * d + 3 * T * ff) + g(T, d, ff)
     dgrad = g(T, ff, d) + 2.0 * 3 * T * ff + g(T, d, 2 * ff) + g(T, d, d) + g(T, d, 3 * d)
     wgrad = g(d, ff, T) + g(2 * ff, d, T) + g(d, d, T) + g(3 * d, d, T)
     head = g(T, V, d, 4) + g(T, d, V) + g(V, d, T)
-    Tv, vd, vff = 48 * 577, 1024, 4096
+    Tv, vd, vff = (16 if CFG5 else 48) * 577, 1024, 4096
+    osz = 2.0  # (the CLIP tower stays 16-bit in the fp8 step)
     vit = 23 * (g(Tv, 3 * vd, vd) + g(Tv, vd, vd) + g(Tv, vff, vd) + g(Tv, vd, vff)) * 3 + g(Tv, vd, 640) * 2 + g(Tv, d, vd) * 3
     return L * (fwd + dgrad + wgrad) + head + vit
 
@@ -73,7 +79,8 @@ def _kernel_rows():
     return rows
 
 
-print(json.dumps({"per_kernel": _kernel_rows(), "kernel": "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)", "launches": launches,
+print(json.dumps({"per_kernel": _kernel_rows(), "kernel": ("scaled-fp8 + bf16 MFMA GEMM kernels (all kernel launches of the two cfg-5 training steps of `bench.py --config cfg5 --steps 1 --warmup 1`)" if CFG5 else
+                             "bf16 MFMA GEMM kernels (all kernel launches of the two cfg-3 training steps of `bench.py --steps 1 --warmup 1`)"), "launches": launches,
                   "steps_profiled": 2, "traffic_bytes_per_step": (read_bytes + write_bytes) / 2, "algorithmic_bytes_per_step": algorithmic_bytes_per_step(),
                   "traffic_over_algorithmic": (read_bytes + write_bytes) / 2 / algorithmic_bytes_per_step(),
                   "kernel_source_stamp": bench.kernel_source_stamp(), "algorithmic_bytes_per_launch": 2 * algorithmic_bytes_per_step() / L,

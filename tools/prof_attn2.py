@@ -17,4 +17,11 @@ o, lse = O.attn_fwd2(q, k, v, B, S, H, D, causal=causal)
 for _ in range(2):
     O.attn_fwd2(q, k, v, B, S, H, D, causal=causal, out=o, lse=lse)
     O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, dq=dqkv[:, :H * D], dk=dqkv[:, H * D:2 * H * D], dv=dqkv[:, 2 * H * D:])
+if causal and os.environ.get("PMC_ALL_BWD_FORMS", "1") == "1":  # the seven-product form of the same backward (attn_bwd3_kv_k without the spill + attn_bwd2_dq_k) and the rounds 2-4 dK|dV kernel
+    for _ in range(2):
+        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, dq=dqkv[:, :H * D], dk=dqkv[:, H * D:2 * H * D], dv=dqkv[:, 2 * H * D:], spill=False)
+    O.attn_bwd_fused_kv(1)
+    for _ in range(2):
+        O.attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, dq=dqkv[:, :H * D], dk=dqkv[:, H * D:2 * H * D], dv=dqkv[:, 2 * H * D:], spill=False)
+    O.attn_bwd_fused_kv(True)
 torch.cuda.synchronize()

@@ -421,7 +421,9 @@ int mh_mask_unpad_index(const void* mask_u8, int64_t* fwd, int64_t* inv, int32_t
  *   err[8]/err[9]: attention_mask of sample err[9] is not a right-padded prefix (popcount != lens[b]): not an error - the host then
  *   routes attention through mh_mask_unpad_index's tables (general key-padding form of llama_flash_attn_monkey_patch.py:87-102)
  *   instead of the lens-only fast path of right-padded batches (collator.py:29-34).
- * ids / labels / mask may each be NULL (skipped).  err is int32[10], shared with mh_splice_index (slots 0-3). */
+ *   err[10]: some sample's mask holds a zero (the batch carries padding).  0 = every sequence is S long: the host then drops the lengths
+ *   and the attention kernels run their no-lengths forms (no masks in the tile loops; backward as five products, mh_attn_bwd2_spill).
+ * ids / labels / mask may each be NULL (skipped).  err is int32[12], shared with mh_splice_index (slots 0-3). */
 int mh_check_inputs(const int64_t* ids, const int64_t* labels, const void* mask_u8, const int32_t* lens, int32_t* err, int B, int S,
                     int V, void* stream);
 int mh_embed_splice_fwd(const int64_t* ids, const int32_t* src, const void* embed, const void* feats,

@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void mask_unpad_index_k(const uint8_t* __restr
 //   err[4] = 1: an input id outside [0, V)      (err[5] = flat position)
 //   err[6] = 1: a label that is neither -100 nor in [0, V)   (err[7] = flat position)
 //   err[8] = 1: attention_mask of sample err[9] is not a right-padded prefix (popcount != 1 + last set position)
+//   err[10] = 1: some sample's mask has a zero (the batch carries padding; 0 = every sequence is S long: the callers then run the
+//                no-lengths forms of the attention kernels - no masks in the tile loops, five-product backward)
 __global__ __launch_bounds__(256) void check_inputs_k(const int64_t* __restrict__ ids, const int64_t* __restrict__ labels,
                                                       const uint8_t* __restrict__ mask, const int32_t* __restrict__ lens,
                                                       int32_t* __restrict__ err, int S, int V) {
@@ -307,7 +309,11 @@ __global__ __launch_bounds__(256) void check_inputs_k(const int64_t* __restrict_
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0 && cnt[0] + cnt[1] + cnt[2] + cnt[3] != lens[b]) { if (atomicExch(&err[8], 1) == 0) err[9] = b; }
+    if (threadIdx.x == 0) {
+      const int n = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+      if (n != lens[b]) { if (atomicExch(&err[8], 1) == 0) err[9] = b; }
+      if (n != S) err[10] = 1;
+    }
   }
 }
 

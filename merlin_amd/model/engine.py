@@ -54,6 +54,7 @@ class HipEngine:
         self.on_backward_begin = None  # callable(fresh: bool) | None
         self.strict_checks = True
         self.parity_fp32 = False  # opt-in checking mode: fp32-store forward (merlin_amd/parity.py)
+        self.keep_full_lengths = False  # tests: pass the per-sample lengths to the attention kernels even when every sequence fills the context
         self.force_unpad = False  # tests: send right-padded masks through the general unpad / pad attention path as well
         # fp8 training step beyond the decoder: lm_head on by default (-0.5 % of a cfg-5 step); the CLIP tower's Linears (K = 1024: their
         # quantisation passes cost more than the fp8 MFMA returns, +0.6 %, profiles/r03_fp8_parts_ab.txt) implemented, tested, off by default
@@ -852,6 +853,7 @@ class HipEngine:
     def _check_errors(self):
         """Reads the device-side validation flags back (raises like the reference would) and returns True when the attention
         mask is NOT a right-padded prefix (left padding, holes): the caller then takes the unpad / pad attention path."""
+        self._mask_all_ones = False
         if self._err is None:
             return False
         err, ev = self._err
@@ -866,6 +868,7 @@ class HipEngine:
             raise IndexError(f"index out of range in self: input_ids holds an id outside [0, vocab_size) at flat position {e[5]}")
         if e[6]:
             raise IndexError(f"Target out of bounds: labels holds a value that is neither -100 nor in [0, vocab_size) at flat position {e[7]}")
+        self._mask_all_ones = not e[10]
         return bool(e[8])
 
     def _splice_geometry(self):
@@ -886,7 +889,7 @@ class HipEngine:
         """One pass of device-side input checks (+ the splice row table when the batch carries images); returns src | None."""
         m = self.model
         dev = self.arena.flat.device
-        err_dev = torch.zeros(10, dtype=torch.int32, device=dev)
+        err_dev = torch.zeros(12, dtype=torch.int32, device=dev)
         src = None
         if use_images:
             rpi, row0, P = self._splice_geometry()
@@ -908,7 +911,7 @@ class HipEngine:
             elif mask is not None:
                 O.check_inputs(None, None, mask, lens, err_dev, m.config.vocab_size)
             if getattr(self, "_err_host", None) is None:
-                self._err_host = torch.empty(10, dtype=torch.int32, pin_memory=True)  # reused: every forward consumes its own check
+                self._err_host = torch.empty(12, dtype=torch.int32, pin_memory=True)  # reused: every forward consumes its own check
             host = self._err_host
             host.copy_(err_dev, non_blocking=True)
             ev = torch.cuda.Event()
@@ -960,6 +963,12 @@ class HipEngine:
         unpad = None
         if attention_mask is not None and (general_mask or self.force_unpad):
             unpad = O.mask_unpad_index(am.contiguous())
+        elif attention_mask is not None and self._mask_all_ones and not self.keep_full_lengths:
+            # the collator's mask of a batch without padding (cfg 3 / cfg 5: every sequence fills the context) is all ones: drop the lengths, so the
+            # attention kernels take their no-lengths forms (llama_flash_attn_monkey_patch.py:76-85, the `key_padding_mask is None` branch:
+            # cu_seqlens = arange) - the flag comes from the same device-side check as the mask classification, read back without a wait
+            lens = None
+            ctx["lens"] = None
         ctx["unpad"] = unpad
         x32 = None
         if inputs_embeds is not None:

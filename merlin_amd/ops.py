@@ -834,6 +834,7 @@ def _delta_ws(B, H, S_pad, device):
 
 
 _spill_cache = {}
+LAST_ATTN_BWD_FORM = None
 ATTN_BWD_SPILL = os.environ.get("MH_ATTN_BWD_SPILL", "1") != "0"  # five-product backward (dS spilled by the dK|dV kernel) where it applies
 
 
@@ -870,6 +871,9 @@ def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk
     delta = _delta_ws(B, H, round_up(S, 64), q.device)  # [delta | lse*log2e]
     use_spill = ATTN_BWD_SPILL if spill is None else spill
     ws = _spill_ws(B, S, H, q.device) if (use_spill and causal and D == 128 and S % 128 == 0 and seqlens is None) else None
+    global LAST_ATTN_BWD_FORM
+    if causal and D == 128:
+        LAST_ATTN_BWD_FORM = "five-product" if ws is not None else "seven-product"  # (tests: which form the last causal D = 128 call took)
     if ws is not None:
         L.check(L.lib().mh_attn_bwd2_spill(p(q), i64(q.stride(0)), p(k), i64(k.stride(0)), p(v), i64(v.stride(0)), p(o), i64(o.stride(0)),
                                            p(do), i64(do.stride(0)), p(lse), p(delta), p(dq), i64(dq.stride(0)), p(dk), i64(dk.stride(0)),
@@ -1034,10 +1038,10 @@ def mask_unpad_index(mask):
 
 
 def check_inputs(ids, labels, mask, lens, err, V):
-    """Device-side validation (ids / labels in range, right-padded mask); flags land in err[4:10] (int32[10])."""
+    """Device-side validation (ids / labels in range, right-padded mask, padding present at all); flags land in err[4:11] (int32[12])."""
     ref = ids if ids is not None else (labels if labels is not None else mask)
     B, S = ref.shape
-    assert err.numel() >= 10 and err.dtype == torch.int32
+    assert err.numel() >= 12 and err.dtype == torch.int32
     L.check(L.lib().mh_check_inputs(p(ids), p(labels), p(mask), p(lens), p(err), i32(B), i32(S), i32(V), _stream()), "mh_check_inputs")
 
 

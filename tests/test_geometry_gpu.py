@@ -191,6 +191,11 @@ def test_packed_sequence_at_benchmark_length_vs_oracle(layout):
     out = model(input_ids=batch["input_ids"].cuda(), attention_mask=batch["attention_mask"].cuda(), labels=batch["labels"].cuda(),
                 images=[im.cuda() for im in batch["images"]])
     out.loss.backward()
+    from merlin_amd import ops as O
+
+    # the collator's all-ones mask of a full sequence is recognised on the device and dropped (engine.forward): the decoder's attention then runs
+    # its no-lengths forms - the backward as FIVE products (dS spilled by the dK|dV kernel) - and THAT is what is held to the oracle below
+    assert O.LAST_ATTN_BWD_FORM == "five-product", O.LAST_ATTN_BWD_FORM
     names = ["lm_head.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight",
              "model.layers.0.self_attn.v_proj.weight", "model.layers.0.mlp.gate_proj.weight", "model.layers.0.input_layernorm.weight",
              "model.projector.projector.weight", "model.vision_tower.vision_tower.vision_model.encoder.layers.0.self_attn.q_proj.weight",

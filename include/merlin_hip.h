@@ -442,6 +442,11 @@ int mh_ce_fwd(const float* logits, int64_t ldl, const int64_t* labels, float* ro
 /* dlogits[t, v] (dt, ld = lddl, zero for v in [V, Vpad)) = gscale/count * (softmax - onehot) */
 int mh_ce_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2,
               void* dlogits, int64_t lddl, int B, int S, int V, int Vpad, float gscale, int dt, void* stream);
+/* The same gradient in COMPACT form: output row r = the gradient of logits row rows[r] (flat position; rows[r] < 0: a zero row), nrows rows.
+ * The reference scores only positions whose shifted label is not -100 (llama_mmgpt.py:92-100); every other row of dlogits is exactly zero, so the
+ * head's dgrad and wgrad contract over the scored rows alone (cfg 3: 603 of 4096 positions per sequence) - engine.backward, `sparse_head`. */
+int mh_ce_bwd_rows(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2, void* dlogits, int64_t lddl,
+                   const int64_t* rows, int nrows, int S, int V, int Vpad, float gscale, int dt, void* stream);
 
 /* ---- optimizer (reference: torch AdamW via HF Trainer, trainer.py:45-74) ------------------- */
 /* p, g are `dt`; m, v fp32.  Decoupled weight decay, bias-corrected; gscale multiplies g (1/world, clip). */

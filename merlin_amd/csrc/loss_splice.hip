@@ -83,15 +83,19 @@ __global__ __launch_bounds__(1024) void ce_reduce_k(const float* __restrict__ ro
 template <int DT>
 __global__ __launch_bounds__(256) void ce_bwd_k(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ labels,
                                                 const float* __restrict__ lse, const float* __restrict__ out2,
-                                                uint16_t* __restrict__ dlogits, int64_t lddl, int S, int V, int Vpad, float gscale) {
-  const int64_t t = blockIdx.x;
-  const int64_t lab = shifted_label(labels, t, S);
+                                                uint16_t* __restrict__ dlogits, int64_t lddl, int S, int V, int Vpad, float gscale,
+                                                const int64_t* __restrict__ rows) {
+  // rows != null: COMPACT form - output row r is the gradient of logits row rows[r] (rows[r] < 0: a zero row)
+  const int64_t r = blockIdx.x;
+  const int64_t tt = rows ? rows[r] : r;
+  const int64_t t = tt < 0 ? 0 : tt;
+  const int64_t lab = tt < 0 ? -100 : shifted_label(labels, t, S);
   const bool scored = (lab >= 0 && lab < V);
   const float cnt = out2[1];
   const float g = (scored && cnt > 0.f) ? gscale / cnt : 0.f;
   const float l = lse[t];
   const float* row = logits + t * ldl;
-  uint16_t* drow = dlogits + t * lddl;
+  uint16_t* drow = dlogits + r * lddl;
   for (int v = threadIdx.x; v < Vpad; v += 256) {
     float d = 0.f;
     if (scored && v < V) d = g * (__expf(row[v] - l) - (v == lab ? 1.f : 0.f));
@@ -353,16 +357,24 @@ extern "C" int mh_ce_fwd(const float* logits, int64_t ldl, const int64_t* labels
   MH_LAUNCH_CHECK();
 }
 
+static int ce_bwd_launch(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2, void* dlogits, int64_t lddl,
+                         int64_t nrows, int S, int V, int Vpad, float gscale, const int64_t* rows, int dt, void* stream) {
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(ce_bwd_k<MH_BF16>, dim3((unsigned)nrows), dim3(256), 0, as_stream(stream), logits, ldl, labels, lse, out2, (uint16_t*)dlogits, lddl, S, V, Vpad, gscale, rows);
+  else if (dt == MH_F16)
+    hipLaunchKernelGGL(ce_bwd_k<MH_F16>, dim3((unsigned)nrows), dim3(256), 0, as_stream(stream), logits, ldl, labels, lse, out2, (uint16_t*)dlogits, lddl, S, V, Vpad, gscale, rows);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
 extern "C" int mh_ce_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2,
                          void* dlogits, int64_t lddl, int B, int S, int V, int Vpad, float gscale, int dt, void* stream) {
   if (!logits || !labels || !lse || !out2 || !dlogits || Vpad < V || lddl < Vpad) return MH_ERR_ARG;
-  const int64_t T = (int64_t)B * S;
-  if (dt == MH_BF16)
-    hipLaunchKernelGGL(ce_bwd_k<MH_BF16>, dim3((unsigned)T), dim3(256), 0, as_stream(stream), logits, ldl, labels, lse, out2, (uint16_t*)dlogits, lddl, S, V, Vpad, gscale);
-  else if (dt == MH_F16)
-    hipLaunchKernelGGL(ce_bwd_k<MH_F16>, dim3((unsigned)T), dim3(256), 0, as_stream(stream), logits, ldl, labels, lse, out2, (uint16_t*)dlogits, lddl, S, V, Vpad, gscale);
-  else return MH_ERR_DTYPE;
-  MH_LAUNCH_CHECK();
+  return ce_bwd_launch(logits, ldl, labels, lse, out2, dlogits, lddl, (int64_t)B * S, S, V, Vpad, gscale, nullptr, dt, stream);
+}
+extern "C" int mh_ce_bwd_rows(const float* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* out2, void* dlogits, int64_t lddl,
+                              const int64_t* rows, int nrows, int S, int V, int Vpad, float gscale, int dt, void* stream) {
+  if (!logits || !labels || !lse || !out2 || !dlogits || !rows || nrows <= 0 || Vpad < V || lddl < Vpad) return MH_ERR_ARG;
+  return ce_bwd_launch(logits, ldl, labels, lse, out2, dlogits, lddl, nrows, S, V, Vpad, gscale, rows, dt, stream);
 }
 
 extern "C" int mh_splice_index(const int64_t* ids, const int32_t* img_offset, int32_t* src, int32_t* err, int B, int S, int P,

@@ -20,6 +20,7 @@ overlaps the rest of the backward (merlin_amd/dp.py).
 from __future__ import annotations
 
 import math
+import os
 import weakref
 
 import torch
@@ -74,6 +75,12 @@ class HipEngine:
         # act = silu(gate) * up from the saved gate|up tensor in the first `mem_act_layers` decoder layers (-0.72 GB and +0.45 ms per layer).
         self.mem_level = 0
         self.mem_act_layers = 16
+        # lm_head backward over the SCORED rows only: the reference's loss ignores every position whose shifted label is -100
+        # (llama_mmgpt.py:92-100), so those rows of dlogits are exactly zero and contribute nothing to d(hidden) = dlogits W and
+        # dW = dlogits^T hidden.  The scored rows (cfg 3: the 603 trajectory positions of each 4096-position sequence) are compacted on the
+        # device (mh_mask_unpad_index over the flat batch; their count is read back without a wait) and both products contract over them alone
+        # whenever they are at most half of the batch.  Exact arithmetic, fewer zero terms; False = the dense products.
+        self.sparse_head = os.environ.get("MH_DENSE_HEAD", "0") != "1"  # (env: A/B switch for benchmarks)
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -1051,6 +1058,19 @@ class HipEngine:
             row_loss, lse, out = O.ce_fwd(logits, labels, V)
             loss = out[2]
             ctx.update(labels=labels, ce_lse=lse, ce_out=out)
+            if want_grad and self.sparse_head and not fp8_head and T % 64 == 0:
+                # scored rows: position (b, s) iff s < S - 1 and labels[b, s + 1] != -100; row tables + count now, the count is read in backward
+                sup = torch.zeros(B, S, dtype=torch.uint8, device=dev)
+                sup[:, :-1] = labels[:, 1:] != -100
+                rows_f, rows_i, cnt = O.mask_unpad_index(sup.view(1, T))
+                if getattr(self, "_sup_ring", None) is None:  # (pinned slots, one per forward in flight: a ring of 16)
+                    self._sup_ring, self._sup_slot = torch.empty(16, dtype=torch.int32, pin_memory=True), 0
+                slot = self._sup_ring[self._sup_slot % 16: self._sup_slot % 16 + 1]
+                self._sup_slot += 1
+                slot.copy_(cnt, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                ctx["scored_rows"] = (rows_f, rows_i, slot, ev)
         ctx.update(hn=hn if want_grad else None, logits=logits if want_grad else None)
         lg = logits.view(B, S, Vpad)[:, :, :V]
         return loss, lg, ctx
@@ -1074,10 +1094,34 @@ class HipEngine:
         # L-1..0, embedding, projector, tower layers, tower embeddings), whatever this rank's batch contained: the
         # data-parallel all-reduce sequence is then identical on all ranks (merlin_amd/dp.py).
         # ---- head ----
-        dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
-        ctx["logits"] = None
         wlm = A.view("lm_head.weight", numel=Vpad * d, shape=(Vpad, d))
-        if ctx.get("fp8_head"):
+        sparse = None
+        if ctx.get("scored_rows") is not None and not ctx.get("fp8_head"):
+            rows_f, rows_i, host, ev = ctx["scored_rows"]
+            ev.synchronize()  # (recorded in the forward: long done)
+            n = int(host[0])
+            npad = _ru(max(n, 1), 256)
+            if 2 * npad <= T:
+                sparse = (rows_f[:npad], rows_i)
+        if sparse is not None:
+            rows_f, rows_i = sparse
+            npad = rows_f.numel()
+            dl_c = O.ce_bwd_rows(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], rows_f, V, Vpad, float(gscale), dt)  # [npad, Vpad], zero rows behind the count
+            ctx["logits"] = None
+            hn_c = O.gather_rows2d(ctx["hn"], rows_f, torch.empty(npad, d, dtype=dt, device=dl_c.device))
+            dhn_c = O.gemm_nt(dl_c, wlm, b_t=True)  # [npad, d]
+            if self._trainable("lm_head.weight"):
+                off = A.offset["lm_head.weight"]
+                O.gemm_nt(dl_c, hn_c, a_t=True, b_t=True, out=A.gflat[off: off + Vpad * d].view(Vpad, d), accum=acc)
+            dhn = O.gather_rows2d(dhn_c, rows_i, torch.empty(T, d, dtype=dt, device=dl_c.device))  # un-scored rows: exact zeros
+            del dl_c, hn_c, dhn_c
+            dlogits = None
+        else:
+            dlogits = O.ce_bwd(ctx["logits"], ctx["labels"], ctx["ce_lse"], ctx["ce_out"], V, Vpad, float(gscale), dt)
+            ctx["logits"] = None
+        if sparse is not None:
+            pass
+        elif ctx.get("fp8_head"):
             train_head = self._trainable("lm_head.weight")
             V128 = _ru(Vpad, 128)  # the dgrad contracts over the (padded) vocabulary in whole 128-blocks: zero columns behind Vpad
             dl8, dlT8 = O.quant_fp8_both(dlogits, c_pad=V128) if train_head else (O.quant_fp8_rows(dlogits, k_pad=V128), None)
@@ -1088,7 +1132,7 @@ class HipEngine:
             del dl8, dlT8
         else:
             dhn = O.gemm_nt(dlogits, wlm, b_t=True)  # [T, d]; B = W^T [d, Vpad]
-        if self._trainable("lm_head.weight") and not ctx.get("fp8_head"):
+        if sparse is None and self._trainable("lm_head.weight") and not ctx.get("fp8_head"):
             if T % 64 == 0:
                 # rows [V, Vpad) of the padded gradient block receive exact zeros (dlogits' pad columns are zero)
                 off = A.offset["lm_head.weight"]

@@ -1078,6 +1078,16 @@ def ce_bwd(logits, labels, lse, out2, V, Vpad, gscale, dtype, out=None):
     return out
 
 
+def ce_bwd_rows(logits, labels, lse, out2, rows, V, Vpad, gscale, dtype):
+    """Compact form of ce_bwd: row r of the result is the gradient of logits row rows[r] (int64 flat positions, < 0: a zero row)."""
+    S = labels.shape[1]
+    n = rows.numel()
+    out = torch.empty(n, Vpad, dtype=dtype, device=logits.device)
+    L.check(L.lib().mh_ce_bwd_rows(p(logits), i64(logits.stride(0)), p(labels), p(lse), p(out2), p(out), i64(out.stride(0)), p(rows), i32(n), i32(S),
+                                   i32(V), i32(Vpad), f32(gscale), i32(dt_of(dtype)), _stream()), "mh_ce_bwd_rows")
+    return out
+
+
 def adamw_(param, grad, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     L.check(L.lib().mh_adamw(p(param), p(grad), p(m), p(v), i64(param.numel()), f32(lr), f32(beta1), f32(beta2), f32(eps), f32(wd),
                              i32(step), f32(gscale), i32(dt_of(param)), _stream()), "mh_adamw")

@@ -203,6 +203,59 @@ def test_fp32_residual_stream_forward_backward_parity(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lm_head_backward_over_the_scored_rows_only(dtype):
+    """engine.sparse_head: positions whose shifted label is -100 have exactly zero rows in dlogits, so the head's dgrad / wgrad contract over the
+    scored rows alone (compacted on the device) when those are at most half of the batch.  Interpair-style batch (labels on the trajectory tail
+    only, like cfg 3): every gradient against the dense products (cosine >= 0.99999, max |diff| <= 2 % of max |g| - fp32 sums of the same non-zero
+    terms in another order, one 16-bit rounding each) and against the fp32 oracle with the usual bounds; the loss is the same number."""
+    from merlin_amd import synth
+    from oracle import cases as C
+    from oracle import ref_cpu as R
+
+    tol = TOL[dtype]
+    cfg = C.tiny_cfg()
+    batch = synth.interpair_batch(B=4, S=512, frames=12, base_vocab=cfg.vocab_size - 3, P=cfg.num_patches, image_size=cfg.v_image_size)
+    n_scored = int((batch["labels"][:, 1:] != -100).sum())
+    assert batch["input_ids"].shape == (4, 512) and 0 < 2 * ((n_scored + 255) // 256 * 256) <= 2048, n_scored  # (988 scored rows of 2048)
+    model = _build(cfg, dtype)
+    grads, losses = {}, {}
+    for sparse in (False, True):
+        for p in model.parameters():
+            p.grad = None
+        model.engine.sparse_head = sparse
+        out = model(**_to_dev(batch))
+        out.loss.backward()
+        grads[sparse] = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+        losses[sparse] = float(out.loss)
+    assert losses[True] == losses[False]
+    bad = []
+    for k, g in grads[False].items():
+        a = grads[True][k]
+        if float(g.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, k
+            continue
+        cos = float((a.reshape(-1).double() @ g.reshape(-1).double()) / (a.double().norm() * g.double().norm()))
+        md = float((a - g).abs().max() / g.abs().max())
+        if cos < 0.99999 or md > 0.02:
+            bad.append((k, cos, md))
+    assert not bad, bad[:6]
+    P = R.make_params(cfg, seed=0, requires_grad=True)
+    loss_ref, _ = R.forward(P, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+    loss_ref.backward()
+    bad = []
+    for k, a in grads[True].items():  # against the oracle: never further away than the dense products (the CLIP q / k gradients of 48 tiny frames are noisy in both)
+        gr = P[k].grad
+        if gr is None or float(gr.abs().max()) == 0.0 or k.endswith("self_attn.k_proj.bias"):
+            continue
+        cs = lambda x: float((x.reshape(-1).double() @ gr.reshape(-1).double()) / (x.double().norm() * gr.double().norm()).clamp_min(1e-30))  # noqa: E731
+        c_sparse, c_dense = cs(a), cs(grads[False][k])
+        if c_sparse < min(tol["cos"], c_dense - 1e-3):
+            bad.append((k, c_sparse, c_dense))
+    assert not bad, bad[:6]
+    assert abs(losses[True] - float(loss_ref)) < tol["loss"] * abs(float(loss_ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name", ["tiny_2img", "tiny_padbatch"])
 def test_mem_level_rederived_activations_give_the_same_gradients(name, dtype):
     """engine.mem_level 1 / 2 (bench.py's slope between 'everything resident' and full layer recompute): the normed GEMM operands h1 / h2 are

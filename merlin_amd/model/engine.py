@@ -81,6 +81,7 @@ class HipEngine:
         # device (mh_mask_unpad_index over the flat batch; their count is read back without a wait) and both products contract over them alone
         # whenever they are at most half of the batch.  Exact arithmetic, fewer zero terms; False = the dense products.
         self.sparse_head = os.environ.get("MH_DENSE_HEAD", "0") != "1"  # (env: A/B switch for benchmarks)
+        self.sparse_last_layer = os.environ.get("MH_DENSE_LAST_LAYER", "0") != "1"  # last decoder layer's MLP / o-proj backward over the scored rows
         self._err = None
         self.weight_version = 0  # bumped whenever parameter VALUES change (optimizer step, loads, repack): derived copies
         self._derived = {}       # (fp8 weights, the K-padded patch-embedding weight) are keyed on it
@@ -811,7 +812,7 @@ class HipEngine:
             self._ready(W.names)
         return dx
 
-    def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh, unpad=None):
+    def _llama_layer_bwd(self, W, x, dy, B, S, lens, saved, fresh, unpad=None, rows=None):
         cfg = self.model.config
         A = self.arena
         d, ff, H, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, head_dim_of(cfg)
@@ -824,23 +825,54 @@ class HipEngine:
         p = W.p
         acc = not fresh
         train = self._trainable(p + "mlp.down_proj.weight")
-        dgu = O.gemm_swiglu_bwd(dy, W.wd, gu)  # dact = dy Wd never leaves the kernel: SwiGLU backward in the epilogue
-        if train:
-            if act is None:  # mem_level 2: not kept
-                act = O.swiglu_fwd(gu)
-            self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
-        del act
-        dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
-        if train:
-            if h2 is None:  # mem_level >= 1: the normed operand is re-derived from the saved 16-bit layer-half input
-                h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
-            self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
-        del dgu, gu, h2
-        dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
-                            dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
-        do = O.gemm_nt(dx2, W.wo, b_t=True)
-        if train:
-            self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
+        if rows is not None:
+            # LAST decoder layer under a sparse loss (engine.sparse_head): dy - the gradient of this layer's output - is exactly zero on every
+            # row the loss does not score (the head's dgrad gathered zero rows there and RMSNorm backward is row-wise), so the MLP half, the
+            # post-attention norm and the o projection of this layer contract / map over the scored rows alone: the rows are gathered into
+            # compact [npad, .] operands (rows_f: flat positions, -1 = zero pad row), run through the same kernels, and the two results the
+            # rest of the backward needs dense - d(attention output) and the residual gradient - are gathered back (rows_i; zero rows elsewhere).
+            rows_f, rows_i = rows
+            npad = rows_f.numel()
+            g2 = lambda t: O.gather_rows2d(t, rows_f, torch.empty(npad, t.shape[1], dtype=t.dtype, device=t.device))  # noqa: E731
+            dy_c, gu_c, x2_c = g2(dy), g2(gu), g2(x2)
+            dgu_c = O.gemm_swiglu_bwd(dy_c, W.wd, gu_c)
+            if train:
+                act_c = g2(act) if act is not None else O.swiglu_fwd(gu_c)
+                self._wgrad(dy_c, act_c, A.gview(p + "mlp.down_proj.weight"), fresh, npad)
+                del act_c
+            del act, gu, gu_c
+            dh2_c = O.gemm_nt(dgu_c, W.wgu, b_t=True)
+            if train:
+                h2_c = g2(h2) if h2 is not None else O.rmsnorm_fwd(x2_c, W.ln2, eps)
+                self._wgrad(dgu_c, h2_c, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, npad)
+                del h2_c
+            del dgu_c, h2
+            dx2_c = O.rmsnorm_bwd(x2_c, W.ln2, dh2_c, eps, dx=dy_c, accumulate_dx=True,
+                                  dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
+            do_c = O.gemm_nt(dx2_c, W.wo, b_t=True)
+            if train:
+                self._wgrad(dx2_c, g2(o), A.gview(p + "self_attn.o_proj.weight"), fresh, npad)
+            do = O.gather_rows2d(do_c, rows_i, torch.empty(T, d, dtype=do_c.dtype, device=do_c.device))
+            dx2 = O.gather_rows2d(dx2_c, rows_i, dy)  # (dy's storage: its values live on in dx2_c)
+            del dy_c, x2_c, dh2_c, dx2_c, do_c
+        else:
+            dgu = O.gemm_swiglu_bwd(dy, W.wd, gu)  # dact = dy Wd never leaves the kernel: SwiGLU backward in the epilogue
+            if train:
+                if act is None:  # mem_level 2: not kept
+                    act = O.swiglu_fwd(gu)
+                self._wgrad(dy, act, A.gview(p + "mlp.down_proj.weight"), fresh, Tpad)
+            del act
+            dh2 = O.gemm_nt(dgu, W.wgu, b_t=True)
+            if train:
+                if h2 is None:  # mem_level >= 1: the normed operand is re-derived from the saved 16-bit layer-half input
+                    h2 = O.rmsnorm_fwd(x2, W.ln2, eps)
+                self._wgrad(dgu, h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh, Tpad)
+            del dgu, gu, h2
+            dx2 = O.rmsnorm_bwd(x2, W.ln2, dh2, eps, dx=dy, accumulate_dx=True,
+                                dw_out=A.gview(p + "post_attention_layernorm.weight") if train else None, dw_accumulate=acc)
+            do = O.gemm_nt(dx2, W.wo, b_t=True)
+            if train:
+                self._wgrad(dx2, o, A.gview(p + "self_attn.o_proj.weight"), fresh, Tpad)
         dqkv = self._attn_bwd(qkv, o, do, lse, B, S, H, D, lens, unpad, packed)
         dh1 = O.gemm_nt(dqkv, W.wqkv, b_t=True)
         if train:
@@ -1152,7 +1184,8 @@ class HipEngine:
             if ctx.get("fp8_train"):
                 dx = self._llama_layer_bwd_fp8(self.llama[i], i, ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh, unpad=ctx.get("unpad"))
             else:
-                dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh, unpad=ctx.get("unpad"))
+                dx = self._llama_layer_bwd(self.llama[i], ctx["xs"][i], dx, B, S, lens, ctx["saves"][i], fresh, unpad=ctx.get("unpad"),
+                                           rows=sparse if (i == len(self.llama) - 1 and self.sparse_last_layer) else None)
             ctx["xs"][i] = None
             ctx["saves"][i] = None
         # ---- embedding + splice ----

@@ -304,8 +304,12 @@ SPLITK_WS_MIN = 256 * 65536  # floats: one round of 256 tiles of fp32 partials (
 def _splitk_workspace(device, numel):
     """fp32 partials of the split-K GEMMs: ONE grow-only buffer per (device, stream).  Launches on one stream are ordered, so
     consecutive GEMMs may share it; two streams never do (a size-keyed, process-global cache let concurrent streams race on the
-    partials and thrashed on variable-length batches).  Never (re)allocated while the stream is being captured into a HIP graph:
-    the caller skips the split path there (_skinny_splitk_ok) - a buffer from the graph's private pool must not outlive it."""
+    partials and thrashed on variable-length batches).  While the stream is being captured into a HIP graph the buffer comes from
+    the graph's own memory pool and is NOT cached (it must not outlive the graph; the pool re-uses the block for the next GEMM of
+    the capture): a captured prefill / wide decode step keeps the split path and with it the eager path's summation order -
+    graph and eager logits stay bit-identical."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(numel, dtype=torch.float32, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < numel:
@@ -319,8 +323,8 @@ def _skinny_splitk_ok(dtype):
     """Split-K for skinny products (profiles/r03_skinny_gemm.txt).  Kept to bf16, the performance dtype: fp16 is the dtype BASELINE's
     logits tolerance is stated in, and its full-depth bound (tests/test_model_gpu.py) is held with the one-pass summation order it was
     measured with - the single-element maximum moves by +-25 % under ANY change of summation order.  MH_SKINNY_SPLITK=0 / =2 force it
-    off / on for every dtype (A/B).  Off while a HIP graph is being captured (no workspace allocation inside a capture)."""
-    if not SKINNY_SPLITK or torch.cuda.is_current_stream_capturing():
+    off / on for every dtype (A/B).  The same decision inside and outside a HIP-graph capture (_splitk_workspace)."""
+    if not SKINNY_SPLITK:
         return False
     return dtype == torch.bfloat16 or SKINNY_SPLITK_ALL
 

@@ -204,8 +204,9 @@ def test_fp32_residual_stream_forward_backward_parity(name, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_lm_head_backward_over_the_scored_rows_only(dtype):
-    """engine.sparse_head: positions whose shifted label is -100 have exactly zero rows in dlogits, so the head's dgrad / wgrad contract over the
-    scored rows alone (compacted on the device) when those are at most half of the batch.  Interpair-style batch (labels on the trajectory tail
+    """engine.sparse_head (+ sparse_last_layer): positions whose shifted label is -100 have exactly zero rows in dlogits, so the head's dgrad /
+    wgrad contract over the scored rows alone (compacted on the device) when those are at most half of the batch - and so do the MLP half, the
+    post-attention norm and the o projection of the LAST decoder layer, whose output gradient is zero on the same rows.  Interpair-style batch (labels on the trajectory tail
     only, like cfg 3): every gradient against the dense products (cosine >= 0.99999, max |diff| <= 2 % of max |g| - fp32 sums of the same non-zero
     terms in another order, one 16-bit rounding each) and against the fp32 oracle with the usual bounds; the loss is the same number."""
     from merlin_amd import synth
@@ -222,7 +223,7 @@ def test_lm_head_backward_over_the_scored_rows_only(dtype):
     for sparse in (False, True):
         for p in model.parameters():
             p.grad = None
-        model.engine.sparse_head = sparse
+        model.engine.sparse_head = model.engine.sparse_last_layer = sparse
         out = model(**_to_dev(batch))
         out.loss.backward()
         grads[sparse] = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
@@ -253,6 +254,20 @@ def test_lm_head_backward_over_the_scored_rows_only(dtype):
             bad.append((k, c_sparse, c_dense))
     assert not bad, bad[:6]
     assert abs(losses[True] - float(loss_ref)) < tol["loss"] * abs(float(loss_ref))
+    # the compact last layer re-derives its operands from compact rows under mem_level 2 as well
+    for p in model.parameters():
+        p.grad = None
+    model.engine.mem_level = 2
+    try:
+        model(**_to_dev(batch)).loss.backward()
+    finally:
+        model.engine.mem_level = 0
+    for k, g in grads[True].items():
+        a = model.get_parameter(k).grad.detach().float().cpu()
+        if float(g.abs().max()) == 0.0:
+            continue
+        cos = float((a.reshape(-1).double() @ g.reshape(-1).double()) / (a.double().norm() * g.double().norm()))
+        assert cos >= 0.9999, (k, cos)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -1200,6 +1200,33 @@ def test_skinny_gemm_split_k_with_epilogues(ops, dtype, M, N, K, monkeypatch):
         assert torch.equal(split[k], again[k]), (k, "deterministic")
 
 
+def test_skinny_gemm_in_a_captured_graph_is_bit_identical_to_eager(ops):
+    """the split-K decision is the same inside a HIP-graph capture as outside (the partials then live in the graph's own pool), so
+    a captured prefill / wide decode step sums in the eager path's order: bit-identical results, replay after replay."""
+    from merlin_amd import ops as O
+    M, N, K = 613, 4096, 11008
+    assert int(O.L.lib().mh_gemm_splitk_max(M, N, K)) > 1 and O._skinny_splitk_ok(torch.bfloat16)
+    a, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, seed=1, scale=0.5)
+    resid = rnd(M, N, dtype=torch.bfloat16, seed=3)
+    eager = (ops.gemm_nt(a, b), ops.gemm_nt(a, b, resid=resid))
+    torch.cuda.synchronize()
+    n_ws = len(O._splitk_ws)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = (ops.gemm_nt(a, b), ops.gemm_nt(a, b, resid=resid))
+    torch.cuda.current_stream().wait_stream(side)
+    assert len(O._splitk_ws) == n_ws  # nothing from the graph's pool was cached
+    for _ in range(2):
+        for o in out:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,vd,vff", [(1154, 128, 256), (27696, 1024, 4096), (600, 192, 520)])
 def test_gemm_with_fused_quick_gelu_is_bit_identical_to_unfused(ops, dtype, T, vd, vff):

@@ -39,6 +39,26 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef MH_W4_TIMING
+// development probe (tools/probes/w4_timing.py): per block {entry, operands of tile 0 landed, main loop done, stores issued} in 100-MHz ticks + where it ran
+__device__ unsigned long long* g_w4_dbg = nullptr;
+__device__ __forceinline__ void w4_stamp(int k) {
+  if (g_w4_dbg && threadIdx.x == 0) {
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    g_w4_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = t;
+    if (k == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_w4_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+#define W4_STAMP(k) w4_stamp(k)
+#else
+#define W4_STAMP(k)
+#endif
+
 // MFMA with the accumulator pinned to AccVGPRs ("+a"): hipcc's allocator otherwise shuttles part of the 256 accumulators
 // between VGPRs and AccVGPRs inside the loop.  Volatile: the issue order below IS the schedule.
 template <int DT>
@@ -179,6 +199,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
   // data + 16 B pad, conflict-free for the 8-byte writes and the 16-byte reads) and writes it out as 16 bytes per lane = 256
   // contiguous bytes per row, 4 rows per instruction.  MH_EPI_ACCUM adds the old 16-bit values in fp32 on the way out.
   __syncthreads();  // every wave is done with the operand tiles in LDS
+  W4_STAMP(5);
   char* stage = smem + wave * W4_CSTAGE;
   const unsigned st_w = lds_addr_of(stage) + (unsigned)(lane & 15) * 272 + (unsigned)(lane >> 4) * 8;
   auto stage8 = [&](const float (&v)[4], auto OFF_) {
@@ -345,6 +366,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     return;
   }
   uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;
+  W4_STAMP(6);
   const bool accum = EK == EK_STD && (g.epi & MH_EPI_ACCUM) != 0;
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
@@ -624,6 +646,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   w4_for<NR>([&](auto R_) { read1(S0{}, S0{}, R_); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   W4_FENCE();
+  W4_STAMP(1);
 
   for (int t = 0; t < nk; t += 2) {  // nk is even: tile t from buffer 0, tile t+1 from buffer 1
     phase_e(S0{}, t);
@@ -633,13 +656,16 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   }
   // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  W4_STAMP(2);
 
   w4_store<DT, EK, false>(g, smem, acc, m0, n0, ky);
+  W4_STAMP(3);
 }
 
 template <int DT, bool AKS, bool BKS, int EK>
 __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  W4_STAMP(0);
   int tm, tn;
   tile_of_block(g, tm, tn);
   w4_tile<DT, AKS, BKS, EK>(g, smem, tm, tn, (int)blockIdx.y);
@@ -1026,3 +1052,10 @@ int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStre
 }
 
 }  // namespace mhgemm
+
+#ifdef MH_W4_TIMING
+extern "C" int mh_w4_timing_buffer(void* buf) {  // 8 x uint64 per block of the next gemm_w4 launches (nullptr: off)
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mhgemm::g_w4_dbg), &p, sizeof(p));
+}
+#endif

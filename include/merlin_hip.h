@@ -180,6 +180,10 @@ void mh_gemm_force_kernel(int which);
  * 16-bit store: bit 0 = TN (weight gradients: both operands K-strided), bit 1 = NN (dgrad), bit 2 = NT (forward; also with a
  * residual), bit 3 = the fp8 training step's exponent-free NT products (gemm_w4_f8).  Default 11 (measured: profiles/r03_gemm_w4_ab.txt). */
 void mh_gemm_w4_policy(int mask);
+/* 128-row block tiles of the 4-wave kernel (a wave owns 64 x 128 outputs) for NT products with few rows - a 613-token prefill
+ * (BASELINE configs[0]/[1]; every `generate` prompt, llama_mmgpt.py:114-134) is 2.4 tiles of 256 rows: 0 = never, 1 (default) = where
+ * they take fewer rounds of the 256 CUs than 256-row tiles, 2 = wherever the form exists (tests / A-B). */
+void mh_gemm_w4_half(int mode);
 /* 256x256-tile kernels: 1 (default) = persistent launch, one block per CU looping over the output tiles with the next tile's
  * first K-tile fetched under the epilogue; 0 = one block per tile (A-B benchmarks). */
 void mh_gemm_persistent(int on);

@@ -52,6 +52,8 @@ def lib() -> C.CDLL:
             _lib.mh_attn_wide_stores(C.c_int(int(os.environ["MH_ATTN_WIDE_STORES"])))
         if os.environ.get("MH_W4_MASK"):  # layouts the auto selection gives to the 4-wave GEMM (bit 0 TN, 1 NN, 2 NT)
             _lib.mh_gemm_w4_policy(C.c_int(int(os.environ["MH_W4_MASK"])))
+        if os.environ.get("MH_W4_HALF"):  # 128-row block tiles of the 4-wave GEMM: 0 never, 1 auto (default), 2 wherever the form exists
+            _lib.mh_gemm_w4_half(C.c_int(int(os.environ["MH_W4_HALF"])))
         if os.environ.get("MH_GEMM_GM"):
             _lib.mh_gemm_raster_group(C.c_int(int(os.environ["MH_GEMM_GM"])))
     return _lib

@@ -18,11 +18,20 @@ __global__ __launch_bounds__(256) void col_absmax_k(const uint16_t* __restrict__
   const int rows_per = (R + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
-    float f[8];
-    unpack8<DT>(*(const uint4*)(x + (int64_t)r * ldx + cv * 8), f);
+  // eight row pieces are requested before any is used (clamped addresses; a repeated last row does not change a maximum): one dependent
+  // round trip per row held this pass at 1.6 TB/s (profiles/r05_step_cfg5_fp8_kernel_stats.txt)
+  const uint16_t* xc = x + cv * 8;
+  for (int r = r0; r < r1; r += 8) {
+    uint4 raw[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(f[i]));
+    for (int u = 0; u < 8; ++u) raw[u] = *(const uint4*)(xc + (int64_t)min(r + u, r1 - 1) * ldx);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float f[8];
+      unpack8<DT>(raw[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(f[i]));
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)

@@ -216,6 +216,20 @@ struct RopeSpec {
 // Measured per bit in the step: profiles/r04_gemm_w4_policy.txt.
 int g_w4_mask = 3 | 8 | 16 | 32 | 64 | 128 | 256;  // (everything: with the prefetching epilogues every form measures at or above the 8-wave kernel)
 extern "C" void mh_gemm_w4_policy(int mask) { g_w4_mask = mask; }
+// 128-row block tiles of the 4-wave kernel (NT products): 0 = never, 1 = where the launch plan below says they take fewer rounds (default),
+// 2 = wherever the kernel exists (tests / A-B)
+int g_w4_half = 1;
+extern "C" void mh_gemm_w4_half(int mode) { g_w4_half = mode; }
+// Rounds of the 256 CUs a product takes in 256-row tiles against 128-row tiles (one block per CU).  A round of half tiles is priced at 0.75 of
+// a round of full ones - measured (profiles/r05_w4_half_ab.txt: 60-67 us against 81-87 for 64 K-tiles): a K-tile of a half tile is half the
+// MFMAs but 48 KiB of operand copies instead of 64, and it is the copies that set the pace of either (~48 GB/s into one CU's LDS).  A 613-token
+// prefill: q|k|v 144 tiles = 1 round vs 240 half tiles = 0.75; gate|up 258 = 2 rounds vs 430 = 1.5; a training batch of 32 768 tokens never
+// gets here (24 vs 36).
+static bool w4_half_pays(int M, int tiles_n, int splits) {
+  const int64_t t256 = (int64_t)((M + 255) / 256) * tiles_n * splits, t128 = (int64_t)((M + 127) / 128) * tiles_n * splits;
+  const double r256 = (double)((t256 + 255) / 256), r128 = 0.75 * (double)((t128 + 255) / 256);
+  return r128 < r256 - 1e-9;
+}
 static bool w4_policy(int a_ks, int b_ks, int M, int N, int K, int epi, const RopeSpec& fx) {
   (void)M; (void)N;
   if (K < 4096) return false;
@@ -618,7 +632,13 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
     const bool fused_any = (g_w4_mask & 128) && (rope.tab || rope.sw_mode == 1);
     const bool fills = big || fused_any || (int64_t)g.tiles_m * g.tiles_n * splits >= 192;
     const bool want = g_force_kernel == 4 || (g_force_kernel == 0 && fills && w4_policy(a_kstrided, b_kstrided, M, N, K, epilogue, rope));
-    if (can && want) return launch_gemm_w4(g, dt, a_kstrided, b_kstrided, as_stream(stream));
+    if (can && want) {
+      if (g_w4_half && w4_has_half(g, a_kstrided, b_kstrided) && (g_w4_half == 2 || w4_half_pays(M, g.tiles_n, splits > 1 ? splits : 1))) {
+        g.tiles_m = (M + 127) / 128;
+        return launch_gemm_w4(g, dt, a_kstrided, b_kstrided, as_stream(stream), 1);
+      }
+      return launch_gemm_w4(g, dt, a_kstrided, b_kstrided, as_stream(stream), 0);
+    }
   }
   if (rope.sw_mode == 1) {  // a tile = 128 gate + 128 up columns
     g.tiles_m = (M + 255) / 256;

@@ -236,7 +236,8 @@ int launch_gemm_nt_w4(const GemmArgs& g, int dt, hipStream_t stream, int var = 0
 // fused RoPE / SwiGLU / SwiGLU-backward forms on the fp32 accumulators; split-K (fp32 partials); K tails of K-strided operands
 bool w4_can_run(const GemmArgs& g, int a_kstrided, int b_kstrided);
 bool w4_has_kernel(const GemmArgs& g, int a_kstrided, int b_kstrided);  // the (epilogue kind, layout) pair is instantiated
-int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream);
+int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream, int half = 0);  // half: 128-row block tiles
+bool w4_has_half(const GemmArgs& g, int a_kstrided, int b_kstrided);
 int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStream_t stream);  // n weight gradients (TN) over one K, one launch
 bool w4_f8_can_run(const GemmArgs& g);  // fp8 operands (no block exponents), see gemm_w4.hip
 bool w4_f8_is_fused(const GemmArgs& g);  // RoPE / SwiGLU / fp32-store kinds (own policy bit)

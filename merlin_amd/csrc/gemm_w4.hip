@@ -73,6 +73,7 @@ constexpr int W4_PART = 256 * 128;     // 32 KiB: 256 rows x 64 k
 constexpr int W4_UNIT = 2 * W4_PART;   // A part + B part of one K-tile
 constexpr int W4_CSTAGE = 128 * 272;   // per-wave C staging slice of the epilogue (128 rows x (256 + 16) B)
 constexpr int W4_LDS = 4 * W4_CSTAGE;  // >= 2 * W4_UNIT: two K-tile buffers during the loop, four C slices after it
+constexpr int W4_LDS_HALF = 3 * 49152; // the 128-row tile: three K-tile buffers of 48 KiB (>= the four C slices)
 
 template <int OFF>
 __device__ __forceinline__ void dsr128(u32x4& d, unsigned addr) {
@@ -83,6 +84,14 @@ __device__ __forceinline__ void dsr64tr(u32x2& d, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+// records of a K-contiguous operand's descriptor for tile t of nk: all of them (-1) while t < nk, none (0) past the end - in SCALAR instructions
+// (written in C, `t < nk ? -1 : 0` and `(t - nk) >> 31` both come out as a VALU select whose result cannot be copied into the SGPR descriptor)
+__device__ __forceinline__ int w4_nrec(int t, int nk) {
+  int d;
+  asm volatile("s_sub_i32 %0, %1, %2\n\ts_ashr_i32 %0, %0, 31" : "=s"(d) : "s"(t), "s"(nk) : "scc");
+  return d;
+}
+#define W4_NREC(t, nk) w4_nrec(t, nk)
 template <int N, typename F>
 __device__ __forceinline__ void w4_for(F&& f) {
   if constexpr (N > 0) {
@@ -113,6 +122,24 @@ struct Sched {
   }
 };
 
+// The half tile (MI = 4): 32 MFMAs per phase, 12 copies per K-tile, M0 write + copy behind the same MFMA; the fragment reads go one to a slot
+// (two where there are more than 16 of them: K-strided B).
+template <int NR>
+struct SchedH {
+  static constexpr int RPS = NR > 16 ? 2 : 1;                          // reads per slot
+  static constexpr int RS = (NR + RPS - 1) / RPS;                      // slots that carry reads
+  static constexpr int B1 = RS + 3;                                    // phase E: lgkmcnt(0) + barrier slot
+  static constexpr int E0 = B1 + 2;                                    // phase E: first copy slot, then every second slot
+  static constexpr int CE = (30 - E0) / 2 + 1 > 6 ? 6 : (30 - E0) / 2 + 1;  // copies issued in phase E
+  static constexpr int O0 = 5;                                         // phase O: copy slots O0, O0 + 4, ...
+  static constexpr int PO = (12 - CE) > 6 ? 3 : 4;
+  static_assert(CE >= 1 && O0 + PO * (12 - CE - 1) <= 31, "copy schedule does not fit the phases");
+  static constexpr bool e_copy(int sl) { return sl >= E0 && (sl - E0) % 2 == 0 && (sl - E0) / 2 < CE; }
+  static constexpr int e_copy_index(int sl) { return (sl - E0) / 2; }
+  static constexpr bool o_copy(int sl) { return sl >= O0 && (sl - O0) % PO == 0 && (sl - O0) / PO < 12 - CE; }
+  static constexpr int o_copy_index(int sl) { return CE + (sl - O0) / PO; }
+};
+
 // Epilogue kinds (one kernel instantiation each: a run-time switch between 64-tile store blocks makes hipcc spill the accumulators
 // around the merge).  The fused forms work on the fp32 ACCUMULATORS - a lane holds a rotary pair (c, c + 64) resp. a (gate, up)
 // pair of one token in two accumulator tiles of its own - and round once, where the 8-wave kernel's staged forms rotate / gate the
@@ -126,17 +153,19 @@ enum { EK_STD = 0,         // 16-bit C through the staged store: plain / residua
 
 // The store phase of both 4-wave kernels (16-bit operands: F8 = false; fp8 operands: F8 = true, where an accumulator is first multiplied by
 // sc_m[row] * sc_n[column] - the per-row scales of the two quantised operands).  `acc` is the wave's 128 x 128 quadrant in accumulator registers.
-template <int DT, int EK, bool F8>
-__device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t (&acc)[8][8], int m0, int n0, int ky) {
+template <int DT, int EK, bool F8, int MI = 8>
+__device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t (&acc)[MI][8], int m0, int n0, int ky) {
   using std::integral_constant;
+  static_assert(MI == 8 || (MI == 4 && !F8), "a wave owns MI x 8 accumulator tiles: 128 x 128 (MI = 8) or 64 x 128 (MI = 4, the 128-row block tile)");
+  constexpr int RW = MI * 16;  // rows per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  float smv[F8 ? 8 : 1];
+  float smv[F8 ? MI : 1];
   float4 snv[F8 ? 8 : 1];
   if constexpr (F8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) smv[i] = g.sc_m[min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1)];
+    for (int i = 0; i < MI; ++i) smv[i] = g.sc_m[min(m0 + wm * RW + i * 16 + (lane & 15), g.M - 1)];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {  // the B row (= output column) behind accumulator tile j; SwiGLU tiles hold 64 gate + 64 up columns per wave
       const int n = EK == EK_SWIGLU ? ((j < 4 ? 0 : g.sw_ff) + n0 + wn * 64 + (j & 3) * 16 + 4 * (lane >> 4)) : (n0 + wn * 128 + j * 16 + 4 * (lane >> 4));
@@ -153,9 +182,9 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
   if constexpr (EK == EK_F32) {
     // fp32 C straight from the accumulators (16 bytes per lane = 64 contiguous bytes per row and instruction)
     float* cb = (float*)g.C + (int64_t)ky * g.c_split;
-    w4_for<64>([&](auto T_) {
+    w4_for<MI * 8>([&](auto T_) {
       constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
-      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+      const int m = m0 + wm * RW + i * 16 + (lane & 15);
       const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
       float v[4];
       val(integral_constant<int, i>{}, integral_constant<int, j>{}, v);
@@ -171,19 +200,19 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     float4 old[2][16];
     auto addr = [&](int tt) {  // clamped (always a valid address; the store below is guarded)
       const int i = tt / 8, j = tt % 8;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int m = min(m0 + wm * RW + i * 16 + (lane & 15), g.M - 1);
       const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
       return (float4*)(cb + (int64_t)m * g.ldc + n);
     };
     w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[0][t] = *addr(t); });
     W4_FENCE();
-    w4_for<4>([&](auto C_) {
+    w4_for<MI / 2>([&](auto C_) {
       constexpr int c = decltype(C_)::value;
-      if constexpr (c + 1 < 4) w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[(c + 1) & 1][t] = *addr((c + 1) * 16 + t); });
+      if constexpr (c + 1 < MI / 2) w4_for<16>([&](auto T_) { constexpr int t = decltype(T_)::value; old[(c + 1) & 1][t] = *addr((c + 1) * 16 + t); });
       W4_FENCE();
       w4_for<16>([&](auto T_) {
         constexpr int t = decltype(T_)::value, tt = c * 16 + t, i = tt / 8, j = tt % 8;
-        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+        const int m = m0 + wm * RW + i * 16 + (lane & 15);
         const int n = n0 + wn * 128 + j * 16 + 4 * (lane >> 4);
         const float4 o = old[c & 1][t];
         float v[4];
@@ -209,9 +238,9 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
   };
   auto fill = [&](auto EPI_) {
     constexpr int EPI = decltype(EPI_)::value;
-    w4_for<64>([&](auto T_) {
+    w4_for<MI * 8>([&](auto T_) {
       constexpr int tt = decltype(T_)::value, i = tt / 8, j = tt % 8;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int m = min(m0 + wm * RW + i * 16 + (lane & 15), g.M - 1);
       const int n = min(n0 + wn * 128 + j * 16 + 4 * (lane >> 4), g.N - 4);
       float v[4];
       val(integral_constant<int, i>{}, integral_constant<int, j>{}, v);
@@ -221,7 +250,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     });
   };
   const unsigned st_r = lds_addr_of(stage) + (unsigned)(lane >> 4) * 272 + (unsigned)(lane & 15) * 16;
-  const int mrow = m0 + wm * 128 + (lane >> 4);
+  const int mrow = m0 + wm * RW + (lane >> 4);
 
   if constexpr (EK == EK_SWIGLU) {
     // quadrant = [64 gate | 64 up] columns n0 + 64 wn .. of ff: accumulator tiles j and j + 4 of a lane are (gate, up) of the same
@@ -233,7 +262,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     uint16_t* gp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + (cq < 8 ? 0 : g.sw_ff) + gcol;
     const bool c_ok = gcol < g.sw_ff;
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
+    for (int part = 0; part < MI / 2; ++part) {
       u32x4 rv[8];
       w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -244,7 +273,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
         if (c_ok && mrow + row < g.M) *(u32x4*)(gp + (int64_t)row * g.ldc) = rv[r];
       }
     }
-    w4_for<32>([&](auto T_) {
+    w4_for<MI * 4>([&](auto T_) {
       constexpr int tt = decltype(T_)::value, i = tt / 4, j = tt % 4;
       float v[4], gt[4], up[4];
       val(integral_constant<int, i>{}, integral_constant<int, j>{}, gt);
@@ -256,10 +285,10 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned st_r2 = lds_addr_of(stage) + (unsigned)(lane >> 3) * 272 + (unsigned)(lane & 7) * 16;
-    const int arow = m0 + wm * 128 + (lane >> 3), acol = n0 + wn * 64 + (lane & 7) * 8;
+    const int arow = m0 + wm * RW + (lane >> 3), acol = n0 + wn * 64 + (lane & 7) * 8;
     uint16_t* ap = (uint16_t*)g.sw_out + (int64_t)arow * g.sw_ldo + acol;
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
+    for (int part = 0; part < MI / 4; ++part) {
       u32x4 rv[8];
       w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 8 * 272>(rv[r], st_r2 + (unsigned)part * 64 * 272); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -282,7 +311,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     float4 tb[2][8];
     auto fetch = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
-      const int m = min(m0 + wm * 128 + i * 16 + (lane & 15), g.M - 1);
+      const int m = min(m0 + wm * RW + i * 16 + (lane & 15), g.M - 1);
       const float4* t4 = (const float4*)(g.rope_tab + ((int64_t)(m % g.rope_S) * 64 + 4 * (lane >> 4)) * 2);
       w4_for<4>([&](auto J_) {
         constexpr int j = decltype(J_)::value;
@@ -292,9 +321,9 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     };
     fetch(integral_constant<int, 0>{});
     W4_FENCE();
-    w4_for<8>([&](auto I_) {
+    w4_for<MI>([&](auto I_) {
       constexpr int i = decltype(I_)::value;
-      if constexpr (i + 1 < 8) fetch(integral_constant<int, i + 1>{});
+      if constexpr (i + 1 < MI) fetch(integral_constant<int, i + 1>{});
       w4_for<4>([&](auto J_) {
         constexpr int j = decltype(J_)::value;
         const float4 t01 = tb[i & 1][2 * j], t23 = tb[i & 1][2 * j + 1];
@@ -340,11 +369,11 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     };
     fetch(integral_constant<int, 0>{});
     W4_FENCE();
-    w4_for<4>([&](auto P_) {
+    w4_for<MI / 2>([&](auto P_) {
       constexpr int part = decltype(P_)::value;
       u32x4 rv[8];
       w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
-      if constexpr (part + 1 < 4) fetch(integral_constant<int, part + 1>{});
+      if constexpr (part + 1 < MI / 2) fetch(integral_constant<int, part + 1>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       W4_FENCE();
 #pragma unroll
@@ -369,7 +398,7 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
   W4_STAMP(6);
   const bool accum = EK == EK_STD && (g.epi & MH_EPI_ACCUM) != 0;
 #pragma unroll
-  for (int part = 0; part < 4; ++part) {
+  for (int part = 0; part < MI / 2; ++part) {
     u32x4 rv[8];
     w4_for<8>([&](auto R_) { constexpr int r = decltype(R_)::value; dsr128<r * 4 * 272>(rv[r], st_r + (unsigned)part * 32 * 272); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -407,20 +436,35 @@ __device__ __forceinline__ unsigned left_after(unsigned span, unsigned off) {
   return d > 0 ? (unsigned)d : 0u;
 }
 
-template <int DT, bool AKS, bool BKS, int EK>
+// MI = accumulator tiles of a wave along M: 8 = the 256 x 256 block tile described above; 4 = a 128 x 256 block tile (a wave owns 64 x 128; the A part
+// of a K-tile is 128 rows = 4 copies per wave, 12 copies and 32 MFMAs per phase) for products with few rows: a 613-token prefill is 2.4 tiles of
+// 256 rows - its gate|up product is 3 x 86 = 258 tiles = two rounds of the 256 CUs for 1.008 rounds of work and q|k|v fills 144 of them; in half
+// tiles they are 430 = 1.7 and 240 = 0.94 half-rounds (profiles/r05_cfg2_fwd_kernel_stats.txt; the host chooses, gemm.hip).
+template <int DT, bool AKS, bool BKS, int EK, int MI = 8>
 __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, int tn, int ky) {
+  static_assert(MI == 8 || MI == 4, "MI");
+  constexpr int RW = MI * 16;      // rows of A per wave
+  constexpr int NCOPY = MI + 8;    // LDS-DMA copies per wave and K-tile: MI of the A part, 8 of the B part
+  constexpr int NS = MI * 8;       // MFMAs per phase
+  // K-tile buffers in LDS.  The full tile has two of 64 KiB.  A half tile's K-tile is 64 MFMAs per wave = ~0.5 us, so copies requested one
+  // tile-and-a-half ahead would have to land inside ~0.7 us - less than an HBM round trip under load (measured: 1.0 us per K-tile with two
+  // buffers, twice its MFMA time): its buffers are packed to 48 KiB (A 16 | B 32) and THREE of them fit, copies run two-and-a-half tiles ahead.
+  constexpr int NBUF = MI == 8 ? 2 : 3;
+  constexpr int BOFF = MI == 8 ? W4_PART : 16384;       // B part of a buffer
+  constexpr int UNIT = MI == 8 ? W4_UNIT : 49152;       // bytes per buffer
+  static_assert(MI == 8 || (!AKS && !BKS), "the half tile is instantiated for NT products (tiles past the end of a K-strided operand's SPLIT are not zeros)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tm * 256, n0 = tn * (EK == EK_SWIGLU ? 128 : 256);
+  const int m0 = tm * (2 * RW), n0 = tn * (EK == EK_SWIGLU ? 128 : 256);
   // K range of this block: all of K, or split `ky` of g.splits (an even number of K-tiles each; K-strided operands may end inside
   // a tile - rows k >= K read as zeros through the buffer descriptor's range check, see copy_ld)
   const int nkt = (g.K + 2 * BK - 1) / (2 * BK) * 2;
   const int per = g.splits > 1 ? ((nkt / 2 + g.splits - 1) / g.splits) * 2 : nkt;
   const int kt0 = ky * per;
   const int nk = min(per, nkt - kt0);
-  constexpr int NRA = AKS ? 16 : 8, NRB = BKS ? 16 : 8, NR = NRA + NRB;
-  using SC = Sched<NR>;
+  constexpr int NRA = AKS ? 2 * MI : MI, NRB = BKS ? 16 : 8, NR = NRA + NRB;
+  using SC = std::conditional_t<MI == 8, Sched<NR>, SchedH<NR>>;
 
   // ---- copies: per-lane source byte offsets (loop-invariant) and the wave's LDS destinations --------------------------------
   // K-contiguous part: wave-load j (0..7) covers part rows 64*wave + 8j .. +7; lane i -> row + (i>>3), physical chunk i&7.
@@ -429,12 +473,12 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if constexpr (!AKS) {
-      const int row = wave * 64 + j * 8 + (lane >> 3);
+      const int row = wave * (MI * 8) + (j & (MI - 1)) * 8 + (lane >> 3);  // (MI = 4: entries 4..7 repeat 0..3 and are never copied)
       voffA[j] = (int)((int64_t)min(m0 + row, g.M - 1) * g.lda * 2 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
     } else {
       const int qd = (j & 3) * 256 + wave * 64 + lane, k = qd >> 4, cc = qd & 15;
       const int col = ((((cc >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 1) | (cc & 1)) * 8;
-      voffA[j] = (int)(((int64_t)k * g.lda + min(m0 + (j >> 2) * 128 + col, g.M - 8)) * 2);
+      voffA[j] = (int)(((int64_t)k * g.lda + min(m0 + (MI == 8 ? (j >> 2) * 128 : 0) + col, g.M - 8)) * 2);
     }
     if constexpr (!BKS) {
       const int row = wave * 64 + j * 8 + (lane >> 3);
@@ -464,12 +508,13 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   const unsigned lds0 = lds_addr_of(smem);
   // the wave's share of a part starts at wave * 8 KiB (K-contiguous: 64 rows) or wave * 1 KiB inside each 4-KiB group (K-strided)
   const unsigned w_kc = lds0 + (unsigned)wave * 8192u, w_ks = lds0 + (unsigned)wave * 1024u;  // (wave-uniform: SGPRs)
+  const unsigned w_kca = lds0 + (unsigned)wave * (unsigned)(MI * 1024);  // A part, K-contiguous: MI * 8 rows per wave
   // the M0 write and the copy are separate single instructions, each placed behind its own MFMA
   auto copy_m0 = [&](auto C_, auto BUF_) {
     constexpr int c = decltype(C_)::value, bu = decltype(BUF_)::value, j = c & 7;
     constexpr bool ks = c < 8 ? AKS : BKS;
-    constexpr int imm = bu * W4_UNIT + (c >> 3) * W4_PART + (ks ? (j >> 2) * 16384 + (j & 3) * 4096 : j * 1024);
-    const unsigned base_ = ks ? w_ks : w_kc;  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
+    constexpr int imm = bu * UNIT + (c >> 3) * BOFF + (ks ? (j >> 2) * 16384 + (j & 3) * 4096 : j * 1024);
+    const unsigned base_ = ks ? w_ks : (c < 8 ? w_kca : w_kc);  // (local copy: clang rejects captured variables as asm operands in nested generic lambdas)
     asm volatile("s_add_u32 m0, %0, %1" ::"s"(base_), "n"(imm) : "scc");
   };
   // K-contiguous operand: fixed descriptor, the K advance is the scalar offset.  K-strided operand: the K advance goes into the
@@ -489,7 +534,8 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
       r.a = i32x4{(int)(uint32_t)ba, (int)(uint32_t)((ba >> 32) & 0xffffu), (int)left_after(spanA, off), 0x00020000};
       r.sa = 0;
     } else {
-      r.a = rsA;
+      if constexpr (NBUF == 3) r.a = i32x4{rsA[0], rsA[1], W4_NREC(t, nk), 0x00020000};  // (three buffers: a tile past the end is copied as ZEROS - no records - and multiplied like any other)
+      else r.a = rsA;
       r.sa = (unsigned)t * (unsigned)(BK * 2);
     }
     if constexpr (BKS) {
@@ -498,7 +544,8 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
       r.b = i32x4{(int)(uint32_t)bb, (int)(uint32_t)((bb >> 32) & 0xffffu), (int)left_after(spanB, off), 0x00020000};
       r.sb = 0;
     } else {
-      r.b = rsB;
+      if constexpr (NBUF == 3) r.b = i32x4{rsB[0], rsB[1], W4_NREC(t, nk), 0x00020000};  // (-1 = every record while t < nk, else 0; scalar arithmetic - a select becomes a VALU instruction here)
+      else r.b = rsB;
       r.sb = (unsigned)t * (unsigned)(BK * 2);
     }
     asm volatile("" : "+s"(r.a), "+s"(r.b), "+s"(r.sa), "+s"(r.sb));
@@ -512,18 +559,21 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
     const unsigned soff = isA ? r.sa : r.sb;
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
   };
-  auto issue_tile = [&](auto BUF_, int t) {  // prologue form (all 16 copies back to back)
+  // copy k of a K-tile (0 .. NCOPY-1) -> copy slot c: 0 .. MI-1 = the A part, 8 .. 15 = the B part
+  auto copy_m0k = [&](auto K_, auto BUF_) { constexpr int k = decltype(K_)::value; copy_m0(std::integral_constant<int, (k < MI ? k : 8 + k - MI)>{}, BUF_); };
+  auto copy_ldk = [&](auto K_, const TileRs& r) { constexpr int k = decltype(K_)::value; copy_ld(std::integral_constant<int, (k < MI ? k : 8 + k - MI)>{}, r); };
+  auto issue_tile = [&](auto BUF_, int t) {  // prologue form (all copies back to back)
     const TileRs r = tile_rs(t);
-    w4_for<16>([&](auto C_) {
-      copy_m0(C_, BUF_);
-      copy_ld(C_, r);
+    w4_for<NCOPY>([&](auto K_) {
+      copy_m0k(K_, BUF_);
+      copy_ldk(K_, r);
     });
   };
 
   using std::integral_constant;
-  f32x4_t acc[8][8];
+  f32x4_t acc[MI][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -531,30 +581,31 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   const int fr = lane & 15, kq = lane >> 4;
   const unsigned swz = (unsigned)((fr >> 1) & 7);
   // K-contiguous: lane row inside the wave's 128 rows, k-step s chunk (4s + kq) ^ swz; fragment q = rows 16q.. = +2048 q
-  unsigned a_kc[2][2], b_kc[2][2];   // [buffer][k-step]
+  unsigned a_kc[NBUF][2], b_kc[NBUF][2];   // [buffer][k-step]
   // K-strided: lane points at row k = 8*kq + (fr>>2), columns 4*(fr&3)..+3 of fragment q's 32-byte chunk (q ^ fx)
-  unsigned a_ks[2][8], b_ks[2][8];   // [buffer][fragment]
+  unsigned a_ks[NBUF][MI], b_ks[NBUF][8];  // [buffer][fragment]
   {
     const unsigned t_rel = (unsigned)(kq * 8 + (fr >> 2)) * 256 + (unsigned)(fr & 3) * 8;
     const unsigned fx = (unsigned)(fr >> 2) | ((unsigned)(kq & 1) << 2);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const unsigned ub = lds0 + (unsigned)b * W4_UNIT;
+    for (int b = 0; b < NBUF; ++b) {
+      const unsigned ub = lds0 + (unsigned)b * UNIT;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        a_kc[b][s] = ub + (unsigned)(wm * 128 + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
-        b_kc[b][s] = ub + W4_PART + (unsigned)(wn * 128 + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
+        a_kc[b][s] = ub + (unsigned)(wm * RW + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
+        b_kc[b][s] = ub + BOFF + (unsigned)(wn * 128 + fr) * 128 + (((4 * s + kq) ^ swz) << 4);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        a_ks[b][q] = ub + (unsigned)wm * 16384 + t_rel + (((unsigned)q ^ fx) << 5);
-        b_ks[b][q] = ub + W4_PART + (unsigned)wn * 16384 + t_rel + (((unsigned)q ^ fx) << 5);
+        // MI = 8: a wave's 128 m are one [64 k][128 m] half-tile; MI = 4: its 64 m are the 32-byte chunks 4 wm .. 4 wm + 3 of the only one
+        if (q < MI) a_ks[b][q] = MI == 8 ? ub + (unsigned)wm * 16384 + t_rel + (((unsigned)q ^ fx) << 5) : ub + t_rel + (((unsigned)(wm * 4 + q) ^ fx) << 5);
+        b_ks[b][q] = ub + BOFF + (unsigned)wn * 16384 + t_rel + (((unsigned)q ^ fx) << 5);
       }
     }
   }
 
-  u32x4 afc[2][8], bfc[2][8];                            // K-contiguous fragments [set][fragment]
-  u32x2 afl[2][8], afh[2][8], bfl[2][8], bfh[2][8];      // K-strided fragments: k 0..3 | 4..7 of the lane's 8 (two tr reads)
+  u32x4 afc[2][MI], bfc[2][8];                           // K-contiguous fragments [set][fragment]
+  u32x2 afl[2][MI], afh[2][MI], bfl[2][8], bfh[2][8];    // K-strided fragments: k 0..3 | 4..7 of the lane's 8 (two tr reads)
 
     // fragment-read instruction r (0..NR-1) of k-step SET from buffer BUF: A's reads first, then B's
   auto read1 = [&](auto BUF_, auto SET_, auto R_) {
@@ -578,10 +629,10 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
       }
     }
   };
-  // MFMA slot sl (0..63): accumulator (sl % 8, sl / 8).  The matrix core takes an independent 16x16x32 MFMA every 16 cycles and a
+  // MFMA slot sl (0..NS-1): accumulator (sl % MI, sl / MI).  The matrix core takes an independent 16x16x32 MFMA every 16 cycles and a
   // wave issues in order, so with ONE wave per SIMD at most one other instruction may sit between two MFMAs.
   auto mfma_slot = [&](auto SET_, auto SL_) {
-    constexpr int s = decltype(SET_)::value, sl = decltype(SL_)::value, i = sl % 8, j = sl / 8;
+    constexpr int s = decltype(SET_)::value, sl = decltype(SL_)::value, i = sl % MI, j = sl / MI;
     u32x4 a, b;
     if constexpr (AKS) a = u32x4{afl[s][i][0], afl[s][i][1], afh[s][i][0], afh[s][i][1]};
     else a = afc[s][i];
@@ -596,18 +647,29 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   // hipcc spills hundreds of registers around control flow that merges paths through these hand-placed asm streams)
   auto phase_e = [&](auto BUF_, int t) {  // MFMAs on set 0 (tile t, k 0..31); fetch set 1 of tile t
     constexpr bool loads = true;
-    const TileRs tr = tile_rs(min(t + 2, nk - 1));
-    w4_for<64>([&](auto SL_) {
+    const TileRs tr = tile_rs(NBUF == 3 ? t + NBUF : min(t + NBUF, nk - 1));
+    w4_for<NS>([&](auto SL_) {
       constexpr int sl = decltype(SL_)::value;
       mfma_slot(S0{}, SL_);
-      if constexpr (sl < NR) read1(BUF_, S1{}, integral_constant<int, sl>{});
+      if constexpr (MI == 8) {
+        if constexpr (sl < NR) read1(BUF_, S1{}, integral_constant<int, sl>{});
+      } else {  // half tile: the reads go two to a slot where there are more than 16 of them
+        constexpr int per = SC::RPS;
+        if constexpr (sl * per < NR) read1(BUF_, S1{}, integral_constant<int, sl * per>{});
+        if constexpr (per == 2 && sl * per + 1 < NR) read1(BUF_, S1{}, integral_constant<int, sl * per + 1>{});
+      }
       if constexpr (loads && sl == SC::B1) {  // every wave has all of tile t in registers -> buffer bu is free
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      if constexpr (loads && SC::e_copy(sl)) {
-        if constexpr ((sl - SC::E0) % SC::PE == 0) copy_m0(integral_constant<int, SC::e_copy_index(sl)>{}, BUF_);
-        else copy_ld(integral_constant<int, SC::e_copy_index(sl)>{}, tr);
+      if constexpr (MI == 8) {
+        if constexpr (loads && SC::e_copy(sl)) {
+          if constexpr ((sl - SC::E0) % SC::PE == 0) copy_m0(integral_constant<int, SC::e_copy_index(sl)>{}, BUF_);
+          else copy_ld(integral_constant<int, SC::e_copy_index(sl)>{}, tr);
+        }
+      } else if constexpr (loads && SC::e_copy(sl)) {  // (M0 write and copy behind the same MFMA)
+        copy_m0k(integral_constant<int, SC::e_copy_index(sl)>{}, BUF_);
+        copy_ldk(integral_constant<int, SC::e_copy_index(sl)>{}, tr);
       }
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -616,31 +678,42 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   auto phase_o = [&](auto BUF_, int t) {  // MFMAs on set 1 (tile t, k 32..63); fetch set 0 of tile t+1
     constexpr int bu = decltype(BUF_)::value;
     constexpr bool loads = true;
-    const TileRs tr = tile_rs(min(t + 2, nk - 1));
-    using NB = integral_constant<int, 1 - bu>;
-    w4_for<64>([&](auto SL_) {
+    const TileRs tr = tile_rs(NBUF == 3 ? t + NBUF : min(t + NBUF, nk - 1));
+    using NB = integral_constant<int, (bu + 1) % NBUF>;
+    w4_for<NS>([&](auto SL_) {
       constexpr int sl = decltype(SL_)::value;
       mfma_slot(S1{}, SL_);
-      if constexpr (sl == 3) {  // tile t+1 has landed for every wave (only phase E's copies of tile t+2 may still be in flight)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SC::CE) : "memory");
+      if constexpr (sl == 3) {  // tile t+1 has landed for every wave (only phase E's copies of tile t+NBUF - and all of the tiles between - may still be in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NCOPY + SC::CE) : "memory");
         __builtin_amdgcn_s_barrier();
       }
       constexpr bool cp = loads && SC::o_copy(sl);
-      if constexpr (cp) {
-        if constexpr ((sl - SC::O0) % SC::PO == 0) copy_m0(integral_constant<int, SC::o_copy_index(sl)>{}, BUF_);
-        else copy_ld(integral_constant<int, SC::o_copy_index(sl)>{}, tr);
+      if constexpr (MI == 8) {
+        if constexpr (cp) {
+          if constexpr ((sl - SC::O0) % SC::PO == 0) copy_m0(integral_constant<int, SC::o_copy_index(sl)>{}, BUF_);
+          else copy_ld(integral_constant<int, SC::o_copy_index(sl)>{}, tr);
+        }
+        constexpr int nread = SC::o_read_index(sl, loads);
+        if constexpr (!cp && sl >= 4 && nread < NR) read1(NB{}, S0{}, integral_constant<int, nread>{});  // (past the last tile: dead data, unused)
+      } else {
+        if constexpr (cp) {
+          copy_m0k(integral_constant<int, SC::o_copy_index(sl)>{}, BUF_);
+          copy_ldk(integral_constant<int, SC::o_copy_index(sl)>{}, tr);
+        }
+        constexpr int per = SC::RPS, r0 = (sl - 4) * per;
+        if constexpr (sl >= 4 && r0 < NR) read1(NB{}, S0{}, integral_constant<int, (r0 < NR ? r0 : 0)>{});
+        if constexpr (sl >= 4 && per == 2 && r0 + 1 < NR) read1(NB{}, S0{}, integral_constant<int, (r0 + 1 < NR ? r0 + 1 : 0)>{});
       }
-      constexpr int nread = SC::o_read_index(sl, loads);
-      if constexpr (!cp && sl >= 4 && nread < NR) read1(NB{}, S0{}, integral_constant<int, nread>{});  // (past the last tile: dead data, unused)
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_FENCE();
   };
 
-  // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-step 0 fragments in registers
+  // prologue: tiles 0 .. NBUF-1 in flight, tile 0 landed, its k-step 0 fragments in registers
   issue_tile(integral_constant<int, 0>{}, 0);
   issue_tile(integral_constant<int, 1>{}, 1);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if constexpr (NBUF == 3) issue_tile(integral_constant<int, 2>{}, 2);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * NCOPY) : "memory");
   __builtin_amdgcn_s_barrier();
   W4_FENCE();
   w4_for<NR>([&](auto R_) { read1(S0{}, S0{}, R_); });
@@ -648,27 +721,41 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   W4_FENCE();
   W4_STAMP(1);
 
-  for (int t = 0; t < nk; t += 2) {  // nk is even: tile t from buffer 0, tile t+1 from buffer 1
-    phase_e(S0{}, t);
-    phase_o(S0{}, t);
-    phase_e(S1{}, t + 1);
-    phase_o(S1{}, t + 1);
+  if constexpr (NBUF == 2) {
+    for (int t = 0; t < nk; t += 2) {  // nk is even: tile t from buffer 0, tile t+1 from buffer 1
+      phase_e(S0{}, t);
+      phase_o(S0{}, t);
+      phase_e(S1{}, t + 1);
+      phase_o(S1{}, t + 1);
+    }
+  } else {
+    using S2 = integral_constant<int, 2>;
+    // tile t from buffer t % 3, whole groups of three: the one or two tiles past the end of K are zeros (tile_rs) - exits from the middle of
+    // the group made hipcc merge three register assignments of the accumulators (256 AGPRs, 20 spills; the straight loop: 128, none)
+    for (int t = 0; t < nk; t += 3) {
+      phase_e(S0{}, t);
+      phase_o(S0{}, t);
+      phase_e(S1{}, t + 1);
+      phase_o(S1{}, t + 1);
+      phase_e(S2{}, t + 2);
+      phase_o(S2{}, t + 2);
+    }
   }
   // the s_nops cover the MFMA -> accumulator-read hazard that the compiler cannot see through the inline-asm MFMAs
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   W4_STAMP(2);
 
-  w4_store<DT, EK, false>(g, smem, acc, m0, n0, ky);
+  w4_store<DT, EK, false, MI>(g, smem, acc, m0, n0, ky);
   W4_STAMP(3);
 }
 
-template <int DT, bool AKS, bool BKS, int EK>
+template <int DT, bool AKS, bool BKS, int EK, int MI = 8>
 __global__ __launch_bounds__(256, 1) void gemm_w4(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   W4_STAMP(0);
   int tm, tn;
   tile_of_block(g, tm, tn);
-  w4_tile<DT, AKS, BKS, EK>(g, smem, tm, tn, (int)blockIdx.y);
+  w4_tile<DT, AKS, BKS, EK, MI>(g, smem, tm, tn, (int)blockIdx.y);
 }
 
 // Grouped weight gradients: up to W4_MAX_GROUP independent TN products out_p[M_p, N_p] (+)= dy_p[T, M_p]^T x_p[T, N_p] over the SAME
@@ -875,14 +962,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_f8(GemmArgs g) {
   w4_store<DT, EK, true>(g, smem, acc, m0, n0, 0);
 }
 
-template <int DT, bool AKS, bool BKS, int EK>
+template <int DT, bool AKS, bool BKS, int EK, int MI = 8>
 int launch_w4(const GemmArgs& g, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_w4<DT, AKS, BKS, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    hipFuncSetAttribute((const void*)gemm_w4<DT, AKS, BKS, EK, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, MI == 8 ? W4_LDS : W4_LDS_HALF);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_w4<DT, AKS, BKS, EK>), dim3(g.tiles_m * g.tiles_n, g.splits > 1 ? g.splits : 1), dim3(256), W4_LDS, stream, g);
+  hipLaunchKernelGGL((gemm_w4<DT, AKS, BKS, EK, MI>), dim3(g.tiles_m * g.tiles_n, g.splits > 1 ? g.splits : 1), dim3(256), MI == 8 ? W4_LDS : W4_LDS_HALF, stream, g);
   MH_LAUNCH_CHECK();
 }
 
@@ -977,9 +1064,23 @@ int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream) {
 }
 
 // (instantiated: every layout for the plain kinds; the fused kinds in the layout their call sites have)
-int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream) {
+// half = 1: the 128-row block tile (g.tiles_m counts 128-row tiles); NT products only (w4_has_half)
+int launch_gemm_w4(const GemmArgs& g, int dt, int a_kstrided, int b_kstrided, hipStream_t stream, int half) {
   const int kind = w4_kind(g);
   const int lay = (a_kstrided ? 2 : 0) | (b_kstrided ? 1 : 0);
+  if (half) {
+    if (lay != 0) return MH_ERR_ARG;
+#define W4_HALF(EK_) return dt == MH_BF16 ? launch_w4<MH_BF16, false, false, EK_, 4>(g, stream) : launch_w4<MH_F16, false, false, EK_, 4>(g, stream)
+    switch (kind) {
+      case EK_STD: W4_HALF(EK_STD);
+      case EK_F32: W4_HALF(EK_F32);
+      case EK_F32ACC: W4_HALF(EK_F32ACC);
+      case EK_ROPE: W4_HALF(EK_ROPE);
+      case EK_SWIGLU: W4_HALF(EK_SWIGLU);
+      default: return MH_ERR_ARG;
+    }
+#undef W4_HALF
+  }
 #define W4_GO(DT_, AKS_, BKS_, EK_) return launch_w4<DT_, AKS_, BKS_, EK_>(g, stream)
 #define W4_LAYOUTS(DT_, EK_)                                                     \
   switch (lay) {                                                                 \
@@ -1023,6 +1124,12 @@ bool w4_has_kernel(const GemmArgs& g, int a_kstrided, int b_kstrided) {
     case EK_SWIGLU_BWD: return lay == 1;
     default: return false;
   }
+}
+
+// the 128-row block tile exists for the NT products (forward: a short prefill's projections, the fp32 logits)
+bool w4_has_half(const GemmArgs& g, int a_kstrided, int b_kstrided) {
+  const int kind = w4_kind(g);
+  return !a_kstrided && !b_kstrided && (kind == EK_STD || kind == EK_F32 || kind == EK_F32ACC || kind == EK_ROPE || kind == EK_SWIGLU);
 }
 
 // grouped weight gradients (see gemm_w4_grouped): n <= W4_MAX_GROUP problems over the same K

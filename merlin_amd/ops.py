@@ -1183,6 +1183,11 @@ def gemm_w4_policy(mask: int):
     L.lib().mh_gemm_w4_policy(i32(mask))
 
 
+def gemm_w4_half(mode: int):
+    """128-row block tiles of the 4-wave GEMM for NT products with few rows (short prefills): 0 = never, 1 = auto (default), 2 = wherever the form exists."""
+    L.lib().mh_gemm_w4_half(i32(mode))
+
+
 def gemm_force_kernel(which: int):
     """0 = auto, 128 / 256 = force that tile size (tests, A/B benchmarks).  Other codes select the development arms and
     exist only in the dev library (tools/dev_arms/)."""

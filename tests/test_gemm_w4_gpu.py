@@ -214,3 +214,38 @@ def test_w4_fp8_fused_forms_vs_dequantised_fp32_and_the_8wave_kernel(ops, dtype)
     resid = rnd(T, 1032, dtype=dtype, seed=7)
     r4 = _with_kernel(ops, 4, lambda: ops.gemm_fp8(a8, wl8, out_dtype=dtype, resid=resid))
     assert relerr(r4, xa @ _deq(wl8).t() + resid.float()) < 3 * EPS16[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 64, 101, 128, 129, 613, 700])
+def test_w4_half_tiles_are_bit_identical_to_the_256_row_tiles(ops, dtype, M):
+    """gemm_w4<..., MI = 4>: the 128-row block tile for products with few rows (a 613-token prefill: q|k|v 144 -> 240 tiles, gate|up 258 -> 430
+    half tiles = 1.7 half-rounds instead of two rounds).  An output element is accumulated over the same K-tiles in the same order by the same
+    MFMA and goes through the same store phase, so every NT form must equal the 256-row kernel BIT FOR BIT: plain / residual / accumulating
+    16-bit stores, fp32 store and accumulate, q|k|v + RoPE, gate|up + SwiGLU."""
+    K, H, D, ff, S = 384, 3, 128, 712, 97
+    a = rnd(M, K, dtype=dtype)
+    w, wqkv, wgu = rnd(520, K, dtype=dtype, seed=1, scale=0.3), rnd(3 * H * D, K, dtype=dtype, seed=2, scale=0.3), rnd(2 * ff, K, dtype=dtype, seed=3, scale=0.3)
+    res = rnd(M, 520, dtype=dtype, seed=4)
+    old16, old32 = rnd(M, 520, dtype=dtype, seed=5), torch.randn(M, 520, device=dev())
+    tab = ops.rope_table(S, D, 10000.0, dev())
+
+    def run(mode):
+        ops.gemm_w4_half(mode)
+        try:
+            def go():
+                o16, o32 = old16.clone(), old32.clone()
+                ops.gemm_nt(a, w, out=o16, accum=True)
+                ops.gemm_nt(a, w, out=o32, accum=True)
+                return (ops.gemm_nt(a, w), ops.gemm_nt(a, w, resid=res), o16, ops.gemm_nt(a, w, out_f32=True), o32,
+                        ops.gemm_nt_rope(a, wqkv, tab, S, H, D), *ops.gemm_swiglu_fwd(a, wgu))
+            return _with_kernel(ops, 4, go)
+        finally:
+            ops.gemm_w4_half(1)
+
+    full, half = run(0), run(2)
+    names = ["plain", "residual", "accumulate16", "fp32", "accumulate32", "rope", "swiglu gu", "swiglu act"]
+    for nm, f, h in zip(names, full, half):
+        assert torch.isfinite(h.float()).all(), nm
+        assert torch.equal(f, h), (nm, float((f.float() - h.float()).abs().max()))
+    assert relerr(half[0], a.float() @ w.float().t()) < 3 * EPS16[dtype]

@@ -494,6 +494,18 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
       voffB[j] = (int)(((int64_t)k * g.ldb + min(n0 + (j >> 2) * 128 + col, g.N - 8)) * 2);
     }
   }
+#if defined(W4H_EXPERIMENT) && W4H_EXPERIMENT == 5  // timing probe: K-contiguous operands fetched as if stored TILE-MAJOR (1 KiB contiguous per copy instruction, 32 KiB per tile and K-tile); results are garbage
+  if constexpr (MI == 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (!AKS) voffA[j] = (m0 / 256) * (g.K / 64) * 32768 + wave * 8192 + j * 1024 + lane * 16;
+      if constexpr (!BKS) voffB[j] = (n0 / 256) * (g.K / 64) * 32768 + wave * 8192 + j * 1024 + lane * 16;
+    }
+  }
+#define W4_KC_STEP 32768u
+#else
+#define W4_KC_STEP (unsigned)(BK * 2)
+#endif
   const unsigned kstepA = AKS ? (unsigned)((int64_t)BK * g.lda * 2) : BK * 2;  // source bytes per K-tile (host guarantees K * ld * 2 < 2^32)
   const unsigned kstepB = BKS ? (unsigned)((int64_t)BK * g.ldb * 2) : BK * 2;
   // operand bases at this block's first K-tile (wave-uniform) and, for K-strided operands, the bytes from there to the end of row K - 1
@@ -536,7 +548,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
     } else {
       if constexpr (NBUF == 3) r.a = i32x4{rsA[0], rsA[1], W4_NREC(t, nk), 0x00020000};  // (three buffers: a tile past the end is copied as ZEROS - no records - and multiplied like any other)
       else r.a = rsA;
-      r.sa = (unsigned)t * (unsigned)(BK * 2);
+      r.sa = (unsigned)t * W4_KC_STEP;
     }
     if constexpr (BKS) {
       const unsigned off = (unsigned)t * kstepB;
@@ -546,18 +558,30 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
     } else {
       if constexpr (NBUF == 3) r.b = i32x4{rsB[0], rsB[1], W4_NREC(t, nk), 0x00020000};  // (-1 = every record while t < nk, else 0; scalar arithmetic - a select becomes a VALU instruction here)
       else r.b = rsB;
-      r.sb = (unsigned)t * (unsigned)(BK * 2);
+      r.sb = (unsigned)t * W4_KC_STEP;
     }
     asm volatile("" : "+s"(r.a), "+s"(r.b), "+s"(r.sa), "+s"(r.sb));
     return r;
   };
+  bool in_loop = false;  // (development probes only)
   auto copy_ld = [&](auto C_, const TileRs& r) {
     constexpr int c = decltype(C_)::value;
     constexpr bool isA = c < 8;
     const int vo = isA ? voffA[c & 7] : voffB[c & 7];
     const i32x4 rs = isA ? r.a : r.b;
     const unsigned soff = isA ? r.sa : r.sb;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
+#if defined(W4H_EXPERIMENT)  // development probes of the main loop (profiles/r05_w4_fetch_probe.txt): 1 / 3 = no copies inside the loop (half tile / every tile), 2 / 4 = the same requests into registers
+    if (in_loop && ((MI == 4 && W4H_EXPERIMENT <= 2) || W4H_EXPERIMENT >= 3)) {
+      if (W4H_EXPERIMENT == 1 || W4H_EXPERIMENT == 3) return;
+      u32x4 sink;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(sink) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+      return;
+    }
+#endif
+#ifndef W4_COPY_MOD
+#define W4_COPY_MOD ""   // (cache-policy bits of the tile copies, a development switch: " nt", " sc1", " sc0 sc1"; measured: profiles/r05_w4_fetch_probe.txt)
+#endif
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen" W4_COPY_MOD " lds" ::"v"(vo), "s"(rs), "s"(soff) : "memory");
   };
   // copy k of a K-tile (0 .. NCOPY-1) -> copy slot c: 0 .. MI-1 = the A part, 8 .. 15 = the B part
   auto copy_m0k = [&](auto K_, auto BUF_) { constexpr int k = decltype(K_)::value; copy_m0(std::integral_constant<int, (k < MI ? k : 8 + k - MI)>{}, BUF_); };
@@ -721,6 +745,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, char* smem, int tm, i
   W4_FENCE();
   W4_STAMP(1);
 
+  in_loop = true;
   if constexpr (NBUF == 2) {
     for (int t = 0; t < nk; t += 2) {  // nk is even: tile t from buffer 0, tile t+1 from buffer 1
       phase_e(S0{}, t);

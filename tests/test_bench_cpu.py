@@ -86,10 +86,11 @@ def test_committed_pmc_traffic_summary_was_taken_on_the_committed_gemm_sources()
     assert t["traffic_over_algorithmic"] > 1.0 and t["traffic_bytes_per_launch"] > 0
 
 
-def test_skinny_split_k_is_a_bf16_launch_plan_and_never_allocates_during_capture(monkeypatch):
+def test_skinny_split_k_is_a_bf16_launch_plan_and_the_same_inside_a_graph_capture(monkeypatch):
     """ops._skinny_splitk_ok: split-K of the skinny projections applies to bf16 (the performance dtype); fp16 - the dtype BASELINE's logits
-    tolerance is stated in - keeps the one-pass summation order its full-depth bounds were measured with; a stream capture turns it off
-    (the workspace must not be allocated from a graph's private pool)."""
+    tolerance is stated in - keeps the one-pass summation order its full-depth bounds were measured with.  The decision is the SAME while a
+    stream is being captured into a HIP graph (graph and eager logits bit-identical): the partials' workspace then comes from
+    the graph's own pool and is not kept in the per-stream cache (ops._splitk_workspace)."""
     import torch
 
     sys.path.insert(0, ROOT)
@@ -101,8 +102,14 @@ def test_skinny_split_k_is_a_bf16_launch_plan_and_never_allocates_during_capture
     assert O._skinny_splitk_ok(torch.bfloat16) and not O._skinny_splitk_ok(torch.float16)
     monkeypatch.setattr(O, "SKINNY_SPLITK_ALL", True)
     assert O._skinny_splitk_ok(torch.float16)
+    monkeypatch.setattr(O, "SKINNY_SPLITK_ALL", False)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
-    assert not O._skinny_splitk_ok(torch.bfloat16)
+    assert O._skinny_splitk_ok(torch.bfloat16) and not O._skinny_splitk_ok(torch.float16)
+    # during a capture the workspace is a fresh allocation (the capture's pool) and the per-stream cache is left alone
+    made = []
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: made.append((a, k)) or "ws")
+    before = dict(O._splitk_ws)
+    assert O._splitk_workspace(torch.device("cpu"), 1234) == "ws" and made and made[0][0] == (1234,) and O._splitk_ws == before
     monkeypatch.setattr(O, "SKINNY_SPLITK", False)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     assert not O._skinny_splitk_ok(torch.bfloat16)

@@ -136,6 +136,14 @@ int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int64_t ldq, fl
                             int R, int C, int dt, void* stream);
 int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* wt_exp,
                            const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, int M, int ff, int K, int dt_out, void* stream);
+/* mh_gemm_fp8_swiglu_bwd that also leaves, in amax_ws [M + 2 ff] (zeroed here), the bit patterns of max |dgu| per row and then per column of the tensor as
+ * stored: taken by the GEMM's store phase itself (order-independent atomicMax) where the 4-wave fp8 kernel runs, by one read of dgu otherwise.
+ * mh_quant_fp8_rows_and_t_pre = mh_quant_fp8_rows_and_t without its maxima pass, fed from such a buffer: together they save one read of the largest
+ * gradient tensor of a decoder layer ([tokens, 2 ff]) per layer and step; the bytes written are identical to the two-pass form's. */
+int mh_gemm_fp8_swiglu_bwd_amax(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt, const void* wt_exp,
+                                const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, unsigned* amax_ws, int M, int ff, int K, int dt_out, void* stream);
+int mh_quant_fp8_rows_and_t_pre(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc, const unsigned* ws,
+                                int R, int C, int dt, void* stream);
 int mh_gemm_splitk_max(int M, int N, int K);
 int mh_gemm_splitk(const void* A, int64_t lda, int a_kstrided, const void* B, int64_t ldb, int b_kstrided, void* C,
                    int64_t ldc, int M, int N, int K, int dt, int accumulate, int out_f32, int splits, float* ws,

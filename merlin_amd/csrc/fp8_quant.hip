@@ -453,6 +453,34 @@ extern "C" int mh_quant_fp8_rows_and_t(const void* x, int64_t ldx, void* q, int6
   }
   MH_LAUNCH_CHECK();
 }
+// The second half of mh_quant_fp8_rows_and_t for a tensor whose maxima are already known: ws = [R row maxima | C column maxima] as bit patterns of
+// non-negative floats (what absmax_rc_k leaves there; mh_gemm_fp8_swiglu_bwd_amax produces them in the GEMM's store phase) - ONE read of x.
+extern "C" int mh_quant_fp8_rows_and_t_pre(const void* x, int64_t ldx, void* q, int64_t ldq, float* sr, void* qt, int64_t ldqt, float* sc,
+                                           const unsigned* ws, int R, int C, int dt, void* stream) {
+  if (!x || !q || !sr || !qt || !sc || !ws || R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldq & 7) || (ldqt & 15) || !aligned16(x) || !aligned16(qt) ||
+      (((uintptr_t)q) & 7u))
+    return MH_ERR_ARG;
+  if (ldqt < (int64_t)(R + 127) / 128 * 128 || ldq < C) return MH_ERR_ARG;
+  if (dt != MH_BF16 && dt != MH_F16) return MH_ERR_DTYPE;
+  const dim3 grid((C + 127) / 128, (R + 127) / 128);
+  const unsigned *rmax = ws, *cmax = ws + R;
+  if (dt == MH_BF16)
+    hipLaunchKernelGGL(quant_fp8_both_k<MH_BF16>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, rmax, cmax, (uint8_t*)q, ldq, sr, (uint8_t*)qt, ldqt, sc, R, C);
+  else
+    hipLaunchKernelGGL(quant_fp8_both_k<MH_F16>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, ldx, rmax, cmax, (uint8_t*)q, ldq, sr, (uint8_t*)qt, ldqt, sc, R, C);
+  MH_LAUNCH_CHECK();
+}
+// row and column maxima of |x| into zeroed rmax [R] / cmax [C] (gemm.hip: the 8-wave fallback of mh_gemm_fp8_swiglu_bwd_amax)
+namespace mhgemm {
+int launch_absmax_rc(const void* x, int64_t ldx, unsigned* rmax, unsigned* cmax, int R, int C, int dt, hipStream_t stream) {
+  if (!x || !rmax || !cmax || (C & 7) || (ldx & 7) || !aligned16(x)) return MH_ERR_ARG;
+  const dim3 grid((C + 127) / 128, (R + 127) / 128);
+  if (dt == MH_BF16) hipLaunchKernelGGL(absmax_rc_k<MH_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)x, ldx, rmax, cmax, R, C);
+  else if (dt == MH_F16) hipLaunchKernelGGL(absmax_rc_k<MH_F16>, grid, dim3(256), 0, stream, (const uint16_t*)x, ldx, rmax, cmax, R, C);
+  else return MH_ERR_DTYPE;
+  MH_LAUNCH_CHECK();
+}
+}  // namespace mhgemm
 extern "C" int mh_max_to_vec(const float* s, int n, float* out, int m, void* stream) {
   if (!s || !out || n <= 0 || m <= 0) return MH_ERR_ARG;
   hipLaunchKernelGGL(max_to_vec_k, dim3(1), dim3(1024), 0, as_stream(stream), s, n, out, m);

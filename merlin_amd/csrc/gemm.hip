@@ -367,7 +367,7 @@ extern "C" int mh_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ld
 
 static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
                          int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
-                         int epilogue, const RopeSpec& fx, void* stream);
+                         int epilogue, const RopeSpec& fx, void* stream, unsigned* amax_ws = nullptr);
 
 extern "C" int mh_gemm_fp8(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp,
                            void* C, int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
@@ -404,10 +404,22 @@ extern "C" int mh_gemm_fp8_swiglu_bwd(const void* dy8, int64_t lddy, const float
   r.sw_mode = 2; r.sw_ff = ff; r.sw_out = dgu; r.sw_ldo = lddgu; r.sw_in = gu; r.sw_ldi = ldgu;
   return gemm_fp8_impl(dy8, lddy, sdy, WdT8, ldw, swt, wt_exp, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt_out, 0, r, stream);
 }
+// The same with the maxima the quantisers behind it need ("produce row / column maxima in the kernels that write the tensors"): on return
+// (stream order) amax_ws [M + 2 ff] holds the bit patterns of max |dgu| per row, then per column, of the tensor AS STORED - taken in the 4-wave kernel's
+// store phase where that kernel runs, by one extra read of dgu (absmax_rc_k) where the 8-wave kernel does; mh_quant_fp8_rows_and_t_pre consumes it.
+extern "C" int mh_gemm_fp8_swiglu_bwd_amax(const void* dy8, int64_t lddy, const float* sdy, const void* WdT8, int64_t ldw, const float* swt,
+                                           const void* wt_exp, const void* gu, int64_t ldgu, void* dgu, int64_t lddgu, unsigned* amax_ws, int M, int ff,
+                                           int K, int dt_out, void* stream) {
+  if (!gu || !dgu || !amax_ws || ff <= 0 || (ff & 7) || (ldgu & 7) || (lddgu & 7) || ((((uintptr_t)gu) | ((uintptr_t)dgu)) & 15u)) return MH_ERR_ARG;
+  if (hipMemsetAsync(amax_ws, 0, (size_t)(M + 2 * ff) * sizeof(unsigned), as_stream(stream)) != hipSuccess) return MH_ERR_ARG;
+  RopeSpec r;
+  r.sw_mode = 2; r.sw_ff = ff; r.sw_out = dgu; r.sw_ldo = lddgu; r.sw_in = gu; r.sw_ldi = ldgu;
+  return gemm_fp8_impl(dy8, lddy, sdy, WdT8, ldw, swt, wt_exp, dgu, lddgu, nullptr, nullptr, 0, M, ff, K, dt_out, 0, r, stream, amax_ws);
+}
 
 static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const void* B8, int64_t ldb, const float* sb, const void* b_exp, void* C,
                          int64_t ldc, const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt_out,
-                         int epilogue, const RopeSpec& fx, void* stream) {
+                         int epilogue, const RopeSpec& fx, void* stream, unsigned* amax_ws) {
   if (!A8 || !B8 || !sa || !sb || !C || M <= 0 || N <= 0 || K <= 0) return MH_ERR_ARG;
   if ((K % 128) || (lda & 15) || (ldb & 15) || !aligned16(A8) || !aligned16(B8)) return MH_ERR_ARG;
   if ((epilogue & MH_EPI_BIAS) && !bias) return MH_ERR_ARG;
@@ -441,10 +453,15 @@ static int gemm_fp8_impl(const void* A8, int64_t lda, const float* sa, const voi
   // 4-wave form (gemm_w4.hip) for exponent-free operands with a plain / residual / accumulating epilogue when the tiles fill the
   // chip; mh_gemm_force_kernel(4) = wherever it can run, (256) = never; auto: mh_gemm_w4_policy bit 3
   // (bit 3 of the policy mask: the plain / residual / accumulating products; bit 8: the fused forms - RoPE, SwiGLU forward / backward, the fp32 logits)
+  g.amax_r = nullptr; g.amax_c = nullptr;
   if (g_force_kernel != 256 && w4_f8_can_run(g) &&
-      (g_force_kernel == 4 || (g_force_kernel == 0 && (g_w4_mask & (w4_f8_is_fused(g) ? 256 : 8)) && (int64_t)g.tiles_m * g.tiles_n >= 192 && K >= 4096)))
+      (g_force_kernel == 4 || (g_force_kernel == 0 && (g_w4_mask & (w4_f8_is_fused(g) ? 256 : 8)) && (int64_t)g.tiles_m * g.tiles_n >= 192 && K >= 4096))) {
+    if (amax_ws && fx.sw_mode == 2) { g.amax_r = amax_ws; g.amax_c = amax_ws + M; }
     return launch_gemm_w4_f8(g, dt_out, as_stream(stream));
-  return launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
+  }
+  const int rc = launch_gemm_nt_256_f8(g, dt_out, as_stream(stream));
+  if (rc != MH_OK || !amax_ws || fx.sw_mode != 2) return rc;
+  return launch_absmax_rc(fx.sw_out, fx.sw_ldo, amax_ws, amax_ws + M, M, 2 * fx.sw_ff, dt_out, as_stream(stream));
 }
 
 // quick-GELU in the GEMM store phase (CLIP MLP; HF CLIPMLP `fc1 -> quick_gelu -> fc2`): forward f1 = x W1^T + b1 AND a = quick_gelu(f1) from one
@@ -569,7 +586,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kstrided, const void* B, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   g.splits = splits; g.c_split = c_split; g.gm = g_gemm_gm;
-  g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_flag = nullptr; g.sc_e_group = 0;
+  g.sc_m = nullptr; g.sc_n = nullptr; g.sc_e = nullptr; g.sc_e_flag = nullptr; g.sc_e_group = 0; g.amax_r = nullptr; g.amax_c = nullptr;
   g.rope_tab = rope.tab; g.rope_S = rope.S; g.rope_D = rope.D; g.rope_cols = rope.cols;
   g.sw_mode = rope.sw_mode; g.sw_ff = rope.sw_ff; g.sw_out = rope.sw_out; g.sw_in = rope.sw_in; g.sw_ldo = rope.sw_ldo; g.sw_ldi = rope.sw_ldi;
   {

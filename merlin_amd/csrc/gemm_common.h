@@ -35,6 +35,10 @@ struct GemmArgs {
   void* sw_out;
   const void* sw_in;
   int64_t sw_ldo, sw_ldi;
+  // fp8 SwiGLU-backward dgrad (4-wave fp8 kernel): when non-null, the store phase also takes the row / column maxima of |dgu| as STORED (16-bit
+  // rounded) by order-independent atomicMax on the values' bit patterns - amax_r [M], amax_c [2 ff], zeroed by the caller: what absmax_rc_k would read back
+  unsigned* amax_r;
+  unsigned* amax_c;
 };
 
 constexpr int BK = 64;
@@ -242,6 +246,7 @@ int launch_gemm_w4_grouped(const GemmArgs* probs, int n, int dt, int gm, hipStre
 bool w4_f8_can_run(const GemmArgs& g);  // fp8 operands (no block exponents), see gemm_w4.hip
 bool w4_f8_is_fused(const GemmArgs& g);  // RoPE / SwiGLU / fp32-store kinds (own policy bit)
 int launch_gemm_w4_f8(const GemmArgs& g, int dt, hipStream_t stream);
+int launch_absmax_rc(const void* x, int64_t ldx, unsigned* rmax, unsigned* cmax, int R, int C, int dt, hipStream_t stream);  // fp8_quant.hip: row and column maxima of |x| in one read
 int launch_gemm_nt_256_f8(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256.hip, fp8 operands + f8f6f4 MFMA
 int launch_gemm_nt_w8(const GemmArgs& g, int dt, hipStream_t stream);      // gemm256w8.hip (8 waves, dense asm stream)
 int launch_gemm_nt_256_m32(const GemmArgs& g, int dt, hipStream_t stream);  // gemm256_m32.hip (32x32x16 arm)

@@ -358,6 +358,13 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
     const uint16_t* gup = (const uint16_t*)g.sw_in + ncl;
     uint16_t* dgp = (uint16_t*)g.sw_out + (int64_t)mrow * g.sw_ldo + ncol;
     uint4 gq[2][8], uq[2][8];
+    // fp8 step: maxima of the stored |dgu| for the quantisers behind this GEMM (GemmArgs::amax_r / amax_c): per lane 8 gate and 8 up columns
+    float cmg[F8 ? 8 : 1], cmu[F8 ? 8 : 1];
+    const bool want_amax = F8 && g.amax_r != nullptr;
+    if constexpr (F8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cmg[k] = cmu[k] = 0.f;
+    }
     auto fetch = [&](auto P_) {
       constexpr int part = decltype(P_)::value;
       w4_for<8>([&](auto R_) {
@@ -385,13 +392,49 @@ __device__ __forceinline__ void w4_store(const GemmArgs& g, char* smem, f32x4_t 
         unpack8<DT>(uq[part & 1][r], ub);
 #pragma unroll
         for (int k = 0; k < 8; ++k) swiglu_bwd1(ga[k], ub[k], d_[k], dg[k], du[k]);
-        if (n_ok && mrow + row < g.M) {
-          *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pack8<DT>(dg);
-          *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pack8<DT>(du);
+        const uint4 pg = pack8<DT>(dg), pu = pack8<DT>(du);
+        const bool ok = n_ok && mrow + row < g.M;
+        if (ok) {
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo) = pg;
+          *(uint4*)(dgp + (int64_t)row * g.sw_ldo + g.sw_ff) = pu;
+        }
+        if constexpr (F8) {
+          if (want_amax) {  // (wave-uniform)
+            float rg[8], ru[8], rm = 0.f;
+            unpack8<DT>(pg, rg);
+            unpack8<DT>(pu, ru);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float a = ok ? fabsf(rg[k]) : 0.f, b = ok ? fabsf(ru[k]) : 0.f;
+              rm = fmaxf(rm, fmaxf(a, b));
+              cmg[k] = fmaxf(cmg[k], a);
+              cmu[k] = fmaxf(cmu[k], b);
+            }
+            // the 16 lanes (lane & 15) of one lane >> 4 hold the 128 gate + 128 up columns of this row
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) rm = fmaxf(rm, __shfl_xor(rm, o, 64));
+            if ((lane & 15) == 0 && mrow + row < g.M && rm > 0.f) atomicMax(g.amax_r + mrow + row, __float_as_uint(rm));
+          }
         }
       }
       W4_FENCE();
     });
+    if constexpr (F8) {
+      if (want_amax) {  // column maxima over the wave's 128 rows: the four lane >> 4 groups hold different rows of the same columns
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          cmg[k] = fmaxf(cmg[k], __shfl_xor(cmg[k], 16, 64)); cmg[k] = fmaxf(cmg[k], __shfl_xor(cmg[k], 32, 64));
+          cmu[k] = fmaxf(cmu[k], __shfl_xor(cmu[k], 16, 64)); cmu[k] = fmaxf(cmu[k], __shfl_xor(cmu[k], 32, 64));
+        }
+        if (lane < 16 && n_ok) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (cmg[k] > 0.f) atomicMax(g.amax_c + ncol + k, __float_as_uint(cmg[k]));
+            if (cmu[k] > 0.f) atomicMax(g.amax_c + g.sw_ff + ncol + k, __float_as_uint(cmu[k]));
+          }
+        }
+      }
+    }
     return;
   }
   uint16_t* cp = (uint16_t*)g.C + (int64_t)mrow * g.ldc + ncol;

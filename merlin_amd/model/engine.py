@@ -61,6 +61,9 @@ class HipEngine:
         # quantisation passes cost more than the fp8 MFMA returns, +0.6 %, profiles/r03_fp8_parts_ab.txt) implemented, tested, off by default
         self.fp8_head = True
         self.fp8_tower = False
+        # fp8 step: the SwiGLU-backward dgrad takes the row / column maxima of dgu in its store phase (mh_gemm_fp8_swiglu_bwd_amax) so that the quantiser
+        # behind it reads the layer's largest gradient tensor once instead of twice; identical bytes (tests/test_fp8_training_gpu.py); env MH_FP8_FUSED_AMAX=0: A/B
+        self.fp8_fused_amax = os.environ.get("MH_FP8_FUSED_AMAX", "1") != "0"
         # Both towers' residual streams are fp32 (updated in place by the accumulating fp32 epilogue of the projections that feed them,
         # read by mh_norm_fwd_f32in); GEMM operands, attention and every saved activation stay 16-bit, the backward runs on the 16-bit
         # copies of the layer inputs the stream's reader emits.  Default ON since round 4: the configuration that is benchmarked is the
@@ -785,11 +788,12 @@ class HipEngine:
         train = self._trainable(p + "mlp.down_proj.weight")
         dt = x.dtype
         dy8, dyT8 = O.quant_fp8_both(dy) if train else (O.quant_fp8_rows(dy), None)
-        dgu = O.gemm_fp8_swiglu_bwd(dy8, Q["wdT"], gu)  # SwiGLU backward in the dgrad's store phase
+        # SwiGLU backward in the dgrad's store phase - which also takes the row / column maxima its quantiser needs (one read of dgu less)
+        dgu, dgu_amax = O.gemm_fp8_swiglu_bwd(dy8, Q["wdT"], gu, want_amax=True) if train and self.fp8_fused_amax else (O.gemm_fp8_swiglu_bwd(dy8, Q["wdT"], gu), None)
         if train:
             self._wgrad_fp8(dyT8, act, s_act, A.gview(p + "mlp.down_proj.weight"), fresh)
         del act, gu, dy8, dyT8
-        dgu8, dguT8 = O.quant_fp8_both(dgu) if train else (O.quant_fp8_rows(dgu), None)
+        dgu8, dguT8 = O.quant_fp8_both(dgu, amax=dgu_amax) if train else (O.quant_fp8_rows(dgu), None)
         dh2 = O.gemm_fp8(dgu8, Q["wguT"], out_dtype=dt)
         if train:
             self._wgrad_fp8(dguT8, h2, s_h2, A.gspan(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", (2 * ff, d)), fresh)

@@ -565,10 +565,12 @@ def quant_fp8_rows_t(x):
 _both_ws = {}
 
 
-def quant_fp8_both(x, c_pad=None):
+def quant_fp8_both(x, c_pad=None, amax=None):
     """x [R, C] (16-bit) -> ((q [R, C], s_row [R]), (qt [C, round_up(R, 128)], s_col [C])): the row-quantised operand (dgrad) and the
     transposed, per-feature-scaled operand (wgrad) of a gradient tensor from two reads of it.  c_pad > C: q is [R, c_pad] with zero
-    columns behind C (a contraction length that is not a whole number of 128-blocks: the vocabulary)."""
+    columns behind C (a contraction length that is not a whole number of 128-blocks: the vocabulary).
+    amax: int32 [R + C] = the tensor's row then column maxima as its producer left them (gemm_fp8_swiglu_bwd(..., want_amax=True)):
+    ONE read of x, identical bytes."""
     R, C_ = x.shape
     Rp = round_up(R, 128)
     if c_pad is not None and c_pad > C_:
@@ -578,6 +580,11 @@ def quant_fp8_both(x, c_pad=None):
     sr = torch.empty(R, dtype=torch.float32, device=x.device)
     qt = torch.empty(C_, Rp, dtype=torch.uint8, device=x.device)
     sc = torch.empty(C_, dtype=torch.float32, device=x.device)
+    if amax is not None:
+        assert amax.dtype == torch.int32 and amax.numel() == R + C_ and amax.is_contiguous()
+        L.check(L.lib().mh_quant_fp8_rows_and_t_pre(p(x), i64(_rowmajor(x)), p(q), i64(q.stride(0)), p(sr), p(qt), i64(Rp), p(sc), p(amax), i32(R), i32(C_),
+                                                    i32(dt_of(x)), _stream()), "mh_quant_fp8_rows_and_t_pre")
+        return (q, sr), (qt, sc)
     ws = _both_ws.get((x.device, R + C_))
     if ws is None:
         if len(_both_ws) > 16:
@@ -600,13 +607,21 @@ def quant_fp8_t_from_rows(x, row_scales):
     return qt, sc
 
 
-def gemm_fp8_swiglu_bwd(dy8, wdt8, gu):
-    """dgu = swiglu_bwd(gu, dy Wd) on the scaled-fp8 MFMA; dy8 = rowquant(dy) [T, d], wdt8 = rowquant(Wd^T) [ff, d]."""
+def gemm_fp8_swiglu_bwd(dy8, wdt8, gu, want_amax=False):
+    """dgu = swiglu_bwd(gu, dy Wd) on the scaled-fp8 MFMA; dy8 = rowquant(dy) [T, d], wdt8 = rowquant(Wd^T) [ff, d].
+    want_amax: returns (dgu, amax int32 [T + 2 ff]) - the row / column maxima of |dgu| taken in the GEMM's store phase (quant_fp8_both(dgu, amax=...))."""
     (qa, sa), (qb, sb, eb) = dy8[:2], _b3(wdt8)
     M, K = qa.shape
     ff = qb.shape[0]
     assert qb.shape[1] == K and gu.shape == (M, 2 * ff)
     dgu = torch.empty_like(gu)
+    if want_amax:
+        amax = torch.empty(M + 2 * ff, dtype=torch.int32, device=gu.device)
+        with _timed("gemm_fp8", 2.0 * M * ff * K):
+            L.check(L.lib().mh_gemm_fp8_swiglu_bwd_amax(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(gu), i64(_rowmajor(gu)),
+                                                        p(dgu), i64(_rowmajor(dgu)), p(amax), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()),
+                    "mh_gemm_fp8_swiglu_bwd_amax")
+        return dgu, amax
     with _timed("gemm_fp8", 2.0 * M * ff * K):
         L.check(L.lib().mh_gemm_fp8_swiglu_bwd(p(qa), i64(qa.stride(0)), p(sa), p(qb), i64(qb.stride(0)), p(sb), p(eb), p(gu), i64(_rowmajor(gu)),
                                                p(dgu), i64(_rowmajor(dgu)), i32(M), i32(ff), i32(K), i32(dt_of(gu)), _stream()), "mh_gemm_fp8_swiglu_bwd")

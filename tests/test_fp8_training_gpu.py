@@ -267,6 +267,36 @@ def test_fp8_swiglu_backward_fused_matches_unfused(dtype):
     assert torch.equal(O.gemm_fp8_swiglu_bwd(dy8, wdT8, gu), O.swiglu_bwd(gu, dact))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("which", [0, 4, 256])
+@pytest.mark.parametrize("T,d,ff", [(600, 256, 640), (1000, 4096, 1408), (253, 128, 264)])
+def test_fp8_swiglu_backward_takes_the_maxima_its_quantiser_needs(dtype, which, T, d, ff):
+    """mh_gemm_fp8_swiglu_bwd_amax: the row / column maxima of |dgu| come out of the GEMM's store phase on the 4-wave fp8 kernel
+    (atomicMax on the stored 16-bit values' bit patterns) and from one read of dgu behind the 8-wave kernel - in both cases EXACTLY the maxima of
+    the stored tensor, so that quant_fp8_both(dgu, amax=...) writes the bytes and scales of the two-pass form; dgu itself is unchanged."""
+    from merlin_amd import ops as O
+
+    g = torch.Generator(device="cuda").manual_seed(T + ff)
+    dy = (torch.randn(T, d, generator=g, device="cuda") * 0.3).to(dtype)
+    wd = (torch.randn(d, ff, generator=g, device="cuda") * 0.05).to(dtype)
+    gu = torch.randn(T, 2 * ff, generator=g, device="cuda").to(dtype)
+    gu[:, 3] = 0  # (a zero gate column: du = 0 there, dg = 0 where dact * up is 0)
+    dy[5] = 0     # a zero row of dact -> a zero row of dgu: maximum 0, scale 1
+    dy8, wdT8 = O.quant_fp8_rows(dy), O.quant_fp8_rows_t(wd)
+    O.gemm_force_kernel(which)
+    try:
+        plain = O.gemm_fp8_swiglu_bwd(dy8, wdT8, gu)
+        dgu, amax = O.gemm_fp8_swiglu_bwd(dy8, wdT8, gu, want_amax=True)
+    finally:
+        O.gemm_force_kernel(0)
+    assert torch.equal(dgu, plain)
+    a = amax.view(torch.float32)
+    assert torch.equal(a[:T], dgu.float().abs().amax(1)) and torch.equal(a[T:], dgu.float().abs().amax(0))
+    (q, sr), (qt, sc) = O.quant_fp8_both(dgu, amax=amax)
+    (q0, sr0), (qt0, sc0) = O.quant_fp8_both(dgu)
+    assert torch.equal(q, q0) and torch.equal(sr, sr0) and torch.equal(qt, qt0) and torch.equal(sc, sc0)
+
+
 @pytest.mark.parametrize("name", ["tiny_2img", "tiny_padbatch", "medium_cfg1"])
 def test_fp8_training_step_vs_reference(name):
     from oracle import cases as C

@@ -10,6 +10,8 @@ import torch
 from merlin_amd import ops as O
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:  # e.g. 256: the 8-wave kernel for everything (mh_gemm_force_kernel)
+    O.gemm_force_kernel(int(sys.argv[1]))
 T, d, ff = 32768, 4096, 11008
 dt = torch.bfloat16
 

@@ -12,7 +12,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // MODE 0 none | 1 m0 write + buffer_load_dwordx4 offen lds | 2 buffer_load_dwordx4 offen -> registers | 3 dwordx2 -> registers | 4 dword -> registers
 //      5 global_load_lds_dwordx4 (saddr + voffset) | 6 = 1 with 32 active lanes | 7 = 2 with a wave-uniform address (off, no VGPR) | 8 = 1, two per slot and
 //      half as many slots (bursts of two) | 9 ds_read_b128 instead (LDS fragment read, for scale)
-template <int MODE, int PER>
+// GEMM-like surroundings (G): 0 none | 1 two ds_read_b128 per slot + lgkmcnt(0) every 8 slots | 2 = 1 + s_barrier every 8 slots | 3 = 2 + vmcnt(8) in front of each barrier
+template <int MODE, int PER, int G = 0>
 __global__ __launch_bounds__(512, 1) void probe_k(const char* __restrict__ src, float* __restrict__ sink, int iters, unsigned window) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -28,12 +29,17 @@ __global__ __launch_bounds__(512, 1) void probe_k(const char* __restrict__ src, 
   const unsigned lds_rd = lds0 + (unsigned)lane * 16u;
   unsigned soff = 0;
   u32x4 sink4 = {0, 0, 0, 0};
+  u32x4 fr[8];
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {  // 16 "copy slots" per iteration
 #pragma unroll
       for (int m = 0; m < PER; ++m) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(c * PER + m) & 15]) : "v"(a), "v"(b));
+      }
+      if constexpr (G >= 1) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fr[(2 * c) & 7]) : "v"(lds_rd) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fr[(2 * c + 1) & 7]) : "v"(lds_rd) : "memory");
       }
       const unsigned so = soff + (unsigned)c * 4096u;
       if constexpr (MODE == 1) {
@@ -67,6 +73,13 @@ __global__ __launch_bounds__(512, 1) void probe_k(const char* __restrict__ src, 
       } else if constexpr (MODE == 9) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(sink4) : "v"(lds_rd) : "memory");
       }
+      if constexpr (G >= 1) {
+        if ((c & 7) == 7) {
+          if constexpr (G >= 3 && MODE != 0 && MODE != 9) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if constexpr (G >= 2) __builtin_amdgcn_s_barrier();
+        }
+      }
       if constexpr (MODE != 0 && MODE != 9) {
         if (c == 15) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // one iteration's requests in flight
       } else if constexpr (MODE == 9) {
@@ -80,18 +93,19 @@ __global__ __launch_bounds__(512, 1) void probe_k(const char* __restrict__ src, 
 #pragma unroll
   for (int j = 0; j < 16; ++j) s += acc[j][0] + acc[j][3];
   s += (float)(sink4[0] & 1u);
+  if constexpr (G >= 1) s += (float)(fr[0][0] & 1u) + (float)(fr[7][3] & 1u);
   if (s == 12345.678f) sink[blockIdx.x * blockDim.x + tid] = s;
 }
 
-template <int MODE, int PER>
+template <int MODE, int PER, int G = 0>
 static float run(const char* src, float* sink, int iters, int waves, int blocks, int reps, unsigned window) {
-  hipFuncSetAttribute((const void*)probe_k<MODE, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+  hipFuncSetAttribute((const void*)probe_k<MODE, PER, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe_k<MODE, PER>), dim3(blocks), dim3(64 * waves), 140 * 1024, 0, src, sink, iters, window);
+  hipLaunchKernelGGL((probe_k<MODE, PER, G>), dim3(blocks), dim3(64 * waves), 140 * 1024, 0, src, sink, iters, window);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe_k<MODE, PER>), dim3(blocks), dim3(64 * waves), 140 * 1024, 0, src, sink, iters, window);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe_k<MODE, PER, G>), dim3(blocks), dim3(64 * waves), 140 * 1024, 0, src, sink, iters, window);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -106,6 +120,9 @@ extern "C" float vmem_issue_probe(int mode, int per, const void* src, void* sink
   float* k = (float*)sink;
   float ms = -1.f;
 #define GO(M, P) if (mode == M && per == P) ms = run<M, P>(s, k, iters, waves, blocks, reps, window);
+#define GG(M, G_) if (mode == M + 100 * G_ && per == 8) ms = run<M, 8, G_>(s, k, iters, waves, blocks, reps, window);
+  GG(0, 1) GG(1, 1) GG(2, 1) GG(0, 2) GG(1, 2) GG(2, 2) GG(0, 3) GG(1, 3) GG(2, 3)
+#undef GG
 #define ALLP(M) GO(M, 4) GO(M, 8) GO(M, 16)
   ALLP(0) ALLP(1) ALLP(2) ALLP(3) ALLP(4) ALLP(5) ALLP(6) ALLP(7) ALLP(8) ALLP(9)
 #undef ALLP

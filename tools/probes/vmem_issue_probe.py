@@ -29,6 +29,14 @@ for waves in (4, 8):
         for mode in range(1, 10):
             v = t(mode, per, waves)
             print(f"    {names[mode]:58s} {v:7.2f} ns per slot  (+{v - base:6.2f} ns per instruction)", flush=True)
+print("--- GEMM-like surroundings (4 waves, 8 MFMAs per slot, L2-resident): +2 ds_read_b128 per slot and lgkmcnt(0) every 8 slots (G1), + s_barrier there (G2), + vmcnt(8) in front of it (G3)")
+for gl in (1, 2, 3):
+    b = t(100 * gl, 8, 4)
+    v1, v2 = t(100 * gl + 1, 8, 4), t(100 * gl + 2, 8, 4)
+    print(f"    G{gl}: no copy {b:7.2f} ns per slot | the GEMM's copy {v1:7.2f} (+{v1 - b:6.2f}) | into registers {v2:7.2f} (+{v2 - b:6.2f})", flush=True)
+    b = t(100 * gl, 8, 4, window=1 << 20)
+    v1 = t(100 * gl + 1, 8, 4, window=1 << 20)
+    print(f"        1 MiB per CU:                          the GEMM's copy {v1:7.2f} (+{v1 - b:6.2f})", flush=True)
 print("--- footprint: 1 MiB per CU (256 MiB for the chip: Infinity Cache / HBM instead of the L2s), 4 waves, 8 MFMAs per slot")
 b = t(0, 8, 4)
 for mode in (1, 2, 4, 6):

@@ -72,6 +72,16 @@ __global__ __launch_bounds__(512, 1) void probe_k(const char* __restrict__ src, 
         }
       } else if constexpr (MODE == 9) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(sink4) : "v"(lds_rd) : "memory");
+      } else if constexpr (MODE == 10) {  // LDS-DMA with a wave-uniform address (no VGPR operand at all)
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(lds0), "n"(0) : "scc");
+        asm volatile("buffer_load_dwordx4 off, %0, %1 lds" ::"s"(rs), "s"(so) : "memory");
+      } else if constexpr (MODE == 11) {  // the copy as two 32-lane halves
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(lds0), "n"(0) : "scc");
+        asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffffffff\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_mov_b64 exec, s[20:21]" ::"v"(vo), "s"(rs), "s"(so)
+                     : "memory", "s20", "s21");
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(lds0), "n"(512) : "scc");
+        asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffffffff\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_mov_b64 exec, s[20:21]" ::"v"(vo), "s"(rs), "s"(so + 512u)
+                     : "memory", "s20", "s21");
       }
       if constexpr (G >= 1) {
         if ((c & 7) == 7) {
@@ -121,7 +131,7 @@ extern "C" float vmem_issue_probe(int mode, int per, const void* src, void* sink
   float ms = -1.f;
 #define GO(M, P) if (mode == M && per == P) ms = run<M, P>(s, k, iters, waves, blocks, reps, window);
 #define GG(M, G_) if (mode == M + 100 * G_ && per == 8) ms = run<M, 8, G_>(s, k, iters, waves, blocks, reps, window);
-  GG(0, 1) GG(1, 1) GG(2, 1) GG(0, 2) GG(1, 2) GG(2, 2) GG(0, 3) GG(1, 3) GG(2, 3)
+  GG(0, 1) GG(1, 1) GG(2, 1) GG(0, 2) GG(1, 2) GG(2, 2) GG(0, 3) GG(1, 3) GG(2, 3) GG(4, 1) GG(6, 1) GG(7, 1) GG(8, 1) GG(10, 1) GG(11, 1)
 #undef GG
 #define ALLP(M) GO(M, 4) GO(M, 8) GO(M, 16)
   ALLP(0) ALLP(1) ALLP(2) ALLP(3) ALLP(4) ALLP(5) ALLP(6) ALLP(7) ALLP(8) ALLP(9)

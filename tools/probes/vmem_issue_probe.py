@@ -37,6 +37,11 @@ for gl in (1, 2, 3):
     b = t(100 * gl, 8, 4, window=1 << 20)
     v1 = t(100 * gl + 1, 8, 4, window=1 << 20)
     print(f"        1 MiB per CU:                          the GEMM's copy {v1:7.2f} (+{v1 - b:6.2f})", flush=True)
+b = t(100, 8, 4)
+for mode, nm in ((1, "the GEMM's copy"), (2, "dwordx4 into registers"), (4, "dword into registers"), (6, "the copy, 32 active lanes"), (11, "the copy as two 32-lane halves"),
+                 (7, "dwordx4 into registers, wave-uniform address (off)"), (10, "LDS-DMA dwordx4, wave-uniform address (off)"), (8, "the copy in bursts of two")):
+    v = t(100 + mode, 8, 4)
+    print(f"    G1 + {nm:52s} {v:7.2f} ns per slot (+{v - b:6.2f})", flush=True)
 print("--- footprint: 1 MiB per CU (256 MiB for the chip: Infinity Cache / HBM instead of the L2s), 4 waves, 8 MFMAs per slot")
 b = t(0, 8, 4)
 for mode in (1, 2, 4, 6):

@@ -55,34 +55,25 @@ def algorithmic_flops_fwd(B, S, n_img, vit_layers_used=23):
     return llama + vit + proj
 
 
-def _alias_layers(P, cfg, R):
-    """Timing only: layer i of both towers points at layer 0's tensors, so a FULL-DEPTH forward runs without drawing 7 B random
-    numbers on the host first (one decoder layer is 0.8 GB in fp32 - far larger than the host caches, so nothing is flattered)."""
-    out = dict(P)
-    for k in list(P):
+def _full_depth_params(P1, cfg, own_memory):
+    """Timing only: a FULL-DEPTH parameter set from ONE layer's random draw per tower, without drawing 7 B normals on the host first.
+    own_memory=True: every layer gets its OWN tensors (layer 0's draw scaled by 1 + i/1024 - a multi-threaded copy, 28 GB of fp32 in all), so no
+    weight byte is ever read twice by one forward; False: layer i points at layer 0's tensors (one decoder layer is 0.8 GB in fp32 - far larger
+    than the host caches, so that flatters nothing either, but it is stated in the line)."""
+    out = dict(P1)
+    for k in list(P1):
         for pre, n in (("model.layers.", cfg.num_hidden_layers), ("model.vision_tower.vision_tower.vision_model.encoder.layers.", cfg.v_num_hidden_layers)):
             if k.startswith(pre + "0."):
                 for i in range(1, n):
-                    out[pre + f"{i}." + k[len(pre) + 2:]] = P[k]
+                    out[pre + f"{i}." + k[len(pre) + 2:]] = (P1[k] * (1.0 + i / 1024.0)) if (own_memory and P1[k].dim() > 1) else P1[k]
     return out
 
 
-def cpu_baseline(seconds_budget=100.0):
-    """The CPU oracle (oracle/ref_cpu.py = a port of the reference's CPU forward, pinned to the reference by golden vectors)
-    timed on this box's host cores, fp32, all torch threads (SURVEY §8d "CPU reference timing"):
-      * `value` = BASELINE cfg 1 at FULL depth (one 336-px image + 32-token caption, S = 613, 24-layer ViT-L with 23 live layers +
-        32-layer Llama-7B + lm_head + CE): 3 warm-up + 5 timed forwards, median - fewer when one forward is too slow for the budget;
-      * `s4096_extrapolated` = one cfg-3 sequence (S = 4096, 6 frames) with 2/23 ViT + 2/32 decoder layers timed and scaled to depth."""
-    import statistics
-
-    from merlin_amd import synth
-    from oracle import ref_cpu as R
-
-    torch.manual_seed(0)
-    # thread count: the box's default pool (half its hardware threads) is not the fastest for S = 613 matmuls; a decoder-MLP-sized
-    # product is timed at a few pool sizes and the fastest is used for everything below (reported as `cores`)
+def _pick_threads(rows):
+    """torch's default pool on these hosts (`threads_default`, all hardware threads the container sees) is not the fastest for the oracle's
+    matmuls: a decoder-MLP-sized product with `rows` rows is timed at a few pool sizes and the fastest is used (reported as `cores`)."""
     all_threads = torch.get_num_threads()
-    xa, wa = torch.randn(613, 4096), torch.randn(11008, 4096)
+    xa, wa = torch.randn(rows, 4096), torch.randn(11008, 4096)
     best = (None, float("inf"))
     for nt in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8), min(all_threads, 16)}, reverse=True):
         torch.set_num_threads(nt)
@@ -94,59 +85,70 @@ def cpu_baseline(seconds_budget=100.0):
         if dt_ < best[1]:
             best = (nt, dt_)
     torch.set_num_threads(best[0])
-    nthreads = best[0]
-    del xa, wa
-    # ---- cfg 1, full depth ----
+    return best[0]
+
+
+def cpu_baseline(seconds_budget=40.0, s4096=True):
+    """The CPU oracle (oracle/ref_cpu.py = a port of the reference's CPU forward, pinned to the reference by golden vectors) timed on this
+    box's host cores, fp32 (SURVEY 8d "CPU reference timing"):
+      * `value` = ONE sequence of the metric's own configuration (BASELINE cfg 3: S = 4096, 6 x 336-px frames; 24-layer ViT-L with 23 live
+        layers + projector + splice + 32-layer Llama-7B + lm_head + shifted CE), full depth, MEASURED: one timed forward (about 100 s of CPU
+        work - the bounded sample is one of the step's eight sequences; the forward has no cross-sequence term, so tokens/s is unaffected);
+      * `cfg1` = BASELINE cfg 1 at full depth (one image + 32-token caption, S = 613): 1 warm-up + 3 timed forwards, median."""
+    import statistics
+
+    from merlin_amd import synth
+    from oracle import ref_cpu as R
+
+    t_begin = time.perf_counter()
+    torch.manual_seed(0)
+    all_threads = torch.get_num_threads()
+    try:
+        import psutil
+
+        ram_gb = psutil.virtual_memory().available / 1e9
+    except Exception:
+        ram_gb = 0.0
+    own = ram_gb > 48.0  # 28.2 GB of fp32 weights + the S = 4096 activations (the [1, 32, S, S] scores are 2.1 GB a copy)
     one = R.OracleConfig(num_hidden_layers=1, v_num_hidden_layers=1)
     full = R.OracleConfig()
     P1 = {k: torch.empty(s).normal_(0, 0.02) if len(s) > 1 else torch.ones(s) for k, s in R.param_shapes(one).items()}
-    P = _alias_layers(P1, full, R)
+    P = _full_depth_params(P1, full, own)
+    weights_note = ("every layer has its own tensors (one random draw per tower, scaled per layer: 28 GB of fp32, no byte read twice)" if own else
+                    f"one layer's random weights aliased across the depth (host RAM available {ram_gb:.0f} GB < 48 GB) - timing only")
+
+    def timed(batch):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            R.forward(P, full, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"])
+        return time.perf_counter() - t0
+
+    # ---- cfg 1, full depth ----
+    nt1 = _pick_threads(613)
     b1 = synth.single_image_batch()
     S1 = int(b1["input_ids"].shape[1])
-    times = []
-    t_begin = time.perf_counter()
-    with torch.no_grad():
-        def fwd():
-            t0 = time.perf_counter()
-            R.forward(P, full, b1["input_ids"], b1["attention_mask"], b1["labels"], b1["images"])
-            return time.perf_counter() - t0
-        first = fwd()
-        n_warm, n_timed = (3, 5) if first * 8 <= seconds_budget else ((1, 3) if first * 4 <= seconds_budget else (1, 1))
-        for _ in range(n_warm - 1):
-            fwd()
-        for _ in range(n_timed):
-            times.append(fwd())
+    first = timed(b1)
+    n_timed = 3 if first * 4 <= seconds_budget else 1
+    times = [timed(b1) for _ in range(n_timed)]
     med = statistics.median(times)
-    del P, P1
-    # ---- one cfg-3 sequence, bounded sample scaled to depth ----
-    cfg = R.OracleConfig(num_hidden_layers=2, v_num_hidden_layers=3)  # select_layer=-2 -> 2 live ViT layers
-    P = {k: torch.empty(s).normal_(0, 0.02) if len(s) > 1 else torch.ones(s) for k, s in R.param_shapes(cfg).items()}
-    batch = synth.interpair_batch(B=1, S=4096)
-    t_parts = {}
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        feats = R.encode_images(P, cfg, batch["images"])
-        t_parts["vit2+proj"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        x = R.splice_image_features(P, cfg, batch["input_ids"], feats)
-        t_parts["splice"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        h = R.llama_forward(P, cfg, x, batch["attention_mask"])
-        t_parts["llama2"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        logits = torch.nn.functional.linear(h, P["lm_head.weight"])
-        R.shifted_ce(logits, batch["labels"])
-        t_parts["head"] = time.perf_counter() - t0
-    est = t_parts["vit2+proj"] * 23 / 2 + t_parts["splice"] + t_parts["llama2"] * 32 / 2 + t_parts["head"]
-    return {"value": round(S1 / med, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
-            "sample": f"BASELINE cfg 1 at full depth (1 x 336px image + 32-token caption, S={S1}; ViT-L 23 live layers + 32 decoder layers + "
-                      f"lm_head + CE), fp32 forward, {n_warm} warm-up + {n_timed} timed, median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f}; "
-                      "one layer's random weights aliased across the depth - timing only)",
-            "seconds_per_forward": round(med, 3), "warmup_forwards": n_warm, "timed_forwards": n_timed,
-            "s4096_extrapolated": {"value": round(4096 / est, 3), "unit": "tokens/s", "extrapolated": True,
-                                   "sample": "1 interpair sequence (S=4096, 6 frames): 2/23 ViT layers + 2/32 decoder layers + lm_head+CE timed, "
-                                             f"scaled to full depth ({est:.1f} s/sequence est.; parts {json.dumps({k: round(v, 2) for k, v in t_parts.items()})})"},
-            "threads_default": all_threads, "wall_s": round(time.perf_counter() - t_begin, 1)}
+    cfg1 = {"value": round(S1 / med, 3), "unit": "tokens/s", "cores": nt1, "seconds_per_forward": round(med, 3), "warmup_forwards": 1, "timed_forwards": n_timed,
+            "sample": f"BASELINE cfg 1 at full depth (1 x 336px image + 32-token caption, S={S1}), fp32 forward, median of {n_timed} (min {min(times):.2f} s, max {max(times):.2f} s)"}
+    out = {"unit": "tokens/s", "kind": "port", "threads_default": all_threads, "weights": weights_note, "cfg1": cfg1,
+           "cores_note": "cores = torch intra-op threads used, the fastest of {T, T/2, T/4, T/8, 16} (T = threads_default, the pool torch sizes to every "
+                         "hardware thread the container sees) on a decoder-MLP-sized matmul of the leg's row count, timed just before the leg"}
+    if not s4096:
+        out.update(value=cfg1["value"], cores=nt1, sample=cfg1["sample"], wall_s=round(time.perf_counter() - t_begin, 1))
+        return out
+    # ---- the metric's configuration: one cfg-3 sequence, full depth, measured ----
+    nt3 = _pick_threads(4096)
+    b3 = synth.interpair_batch(B=1, S=4096)
+    t3 = timed(b3)
+    out.update(value=round(4096 / t3, 3), cores=nt3, seconds_per_forward=round(t3, 2), warmup_forwards=0, timed_forwards=1, measured=True,
+               sample="1 of the step's 8 interpair sequences (BASELINE cfg 3: S=4096, 6 x 336px frames; ViT-L 23 live layers + mlp projector + splice + 32 decoder "
+                      f"layers + lm_head + shifted CE), fp32 forward at FULL depth, one timed forward = {t3:.1f} s on {nt3} threads (pool and pages warmed "
+                      "by the cfg-1 forwards just before)",
+               wall_s=round(time.perf_counter() - t_begin, 1))
+    return out
 
 
 def parse_args(argv=None):
@@ -184,6 +186,10 @@ def parse_args(argv=None):
                     "as every gradient bucket becomes final, a side stream streams it twice through BLOCKS workgroups (tools/probes/hbm_probe.so: the "
                     "CU and HBM footprint of a ring all-reduce's kernels - RCCL itself moves nothing in a group of one rank); the line reports the "
                     "bytes and the time the compute stream waited at the end of backward")
+    ap.add_argument("--rotate", type=int, default=4, metavar="N", help="distinct seeded batches cycled through warm-up and the timed steps (default 4: every "
+                    "step sees other token ids and images than the step before, as in training; all of them resident in HBM before the timed region)")
+    ap.add_argument("--same-batch", action="store_true", help="feed ONE batch to every step (rounds 1-5; the loss then falls to ~0.3 inside the run and "
+                    "dlogits / gradients shrink: A/B against the rotated default in profiles/r06_batch_rotation_ab.txt)")
     ap.add_argument("--no-cfg5-extra", action="store_true", help="skip the cfg-5 (S=8192 interleave, fp8 weight path) row of the N=1 line's `extras`")
     return ap.parse_args(argv)
 
@@ -314,9 +320,15 @@ def main(argv=None):
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        rccl_log = None
         if dry:
             dist.init_process_group("gloo")
         else:
+            if rank == 0 and "NCCL_DEBUG" not in os.environ:
+                # RCCL's own choice of algorithm / protocol per collective size: its TUNING lines ("<coll>: N Bytes -> Algo a proto p time t"), rank 0
+                # only, into a file (one line per enqueued collective: ~35 per step, microseconds each), parsed once after the timed region
+                rccl_log = f"/tmp/mh_rccl_tuning_{os.getpid()}.log"
+                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="TUNING", NCCL_DEBUG_FILE=rccl_log)
             dist.init_process_group("nccl", device_id=dev)
 
     def all_max(x):
@@ -366,17 +378,22 @@ def main(argv=None):
         if args.fp8_forward:
             assert args.fwd_only, "--fp8-forward is forward-only"
             model.fp8_forward = True
+        n_rot = 1 if (args.same_batch or args.fwd_only) else max(1, args.rotate)
+        more = []  # batches 1 .. n_rot-1 of the rotation (batch j of rank r is drawn with the seeds of "rank" r + world * j: no two alike in the job)
         if args.config == "cfg3":
             B = args.batch or 8
             batch = synth.interpair_batch(B=B, S=4096, rank=rank)
+            more = [synth.interpair_batch(B=B, S=4096, rank=rank + world * j) for j in range(1, n_rot)]
             workload = f"interpair: B={B}/GPU x S=4096 (6 x 336px frames + trajectory text), ViT-L/14-336 + mlp projector + Llama-7B"
         elif args.config == "cfg3-ragged":
             B = args.batch or 8
             batch = synth.interpair_batch(B=B, S=4096, rank=rank, ragged=True)
+            more = [synth.interpair_batch(B=B, S=4096, rank=rank + world * j, ragged=True) for j in range(1, n_rot)]
             workload = f"interpair ragged: B={B}/GPU, lengths <= 4096 right-padded (key-padding branch), 6 frames, ViT-L/14-336 + mlp + Llama-7B"
         elif args.config in ("cfg5", "cfg5-bf16"):
             B = args.batch or 4
             batch = synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank)
+            more = [synth.interleave_batch(B=B, S=8192, n_images=4, rank=rank + world * j) for j in range(1, n_rot)]
             if args.config == "cfg5":
                 args.fp8_train = True
                 workload = f"interleave (MMC4-style): B={B}/GPU x S=8192, 4 images per document, fp8 (e4m3) MFMA weight path for the decoder's Linear layers and lm_head"
@@ -404,6 +421,9 @@ def main(argv=None):
                         images=[im.to(dev) for im in b["images"]])
 
         dbatch = to_dev(batch)
+        dbatches = [dbatch] + [to_dev(b) for b in more]  # (cfg 2 is one fixed sample: nothing to rotate)
+        n_tok_rot = [n_tok] + [int(b["attention_mask"].sum()) for b in more]
+        del more
         # the reference's recipe (pretrain.sh:23-29): --llrd, lr 5e-5, beta2 0.95, wd 0.05, cosine warm-up; HF's default
         # max_grad_norm=1.0 clipping - all of it inside the timed step
         opt = FusedAdamW(eng, lr=5e-5, betas=(0.9, 0.95), weight_decay=0.05, lr_scale_fn=vit_lr_scale)
@@ -452,11 +472,15 @@ def main(argv=None):
             opt.zero_grad()
             return out.loss
 
+        calls = [0]
+
         def step():
             if args.fwd_only:
                 with torch.no_grad():
                     return model(**dbatch).loss
-            return train_step(dbatch)
+            db = dbatches[calls[0] % len(dbatches)]
+            calls[0] += 1
+            return train_step(db)
 
     loss_first = None
     for wi in range(args.warmup):
@@ -533,7 +557,11 @@ def main(argv=None):
             fwd_dt = time.perf_counter() - tf0
         fwd_ms = all_max(fwd_dt) / nf * 1e3
     dt = all_max(dt)
-    n_tok_all = all_sum_int(n_tok)
+    if dry or args.fwd_only:
+        n_tok_timed = n_tok * args.steps
+    else:  # the positions the timed steps actually processed (step i of the run fed batch i mod n_rot; warm-up steps came first)
+        n_tok_timed = sum(n_tok_rot[(args.warmup + i) % len(n_tok_rot)] for i in range(args.steps))
+    n_tok_all = all_sum_int(n_tok_timed) / args.steps
     per_rank = None
     if dp:  # per-rank peak HBM and communication times, gathered on rank 0
         mine = torch.tensor([peak_gb, comm["comm_ms_total"] / args.steps, comm["comm_ms_exposed"] / args.steps], device=dev, dtype=torch.float64)
@@ -553,7 +581,13 @@ def main(argv=None):
     ach = work / (gms * 1e-3) / 1e12
     peak = PEAK_FP8_TFLOPS if fp8_dom else PEAK_BF16_TFLOPS
     traffic, traffic_unit = read_traffic(args)
-    step_desc = "fwd only" if args.fwd_only else "fwd+bwd" + (" (layer recompute)" if not eng.save_activations else " (activations resident)") + "+allreduce+adamw"
+    step_desc = "fwd only" if args.fwd_only else ("fwd+bwd" + (" (layer recompute)" if not eng.save_activations else " (activations resident)") +
+                                                 ("+allreduce" if dp else "") + "+clip+adamw")
+    # FLOPs the step EXECUTED: every GEMM launch's 2*M*N*K as launched (event-timed profile of the timed steps: the scored-rows backward of the head
+    # and the last layer contracts over ~15 % of the rows, which `useful` = 3 x forward still counts in full) + attention at the same 3 x convention
+    att_fwd = 0.0 if dry else (B * 32 * 2.0 * S * S * 4096 + n_img * 23 * 4.0 * 577 * 577 * 1024)
+    gemm_exec = (prof.get("gemm_nt", (0, 0.0, 0.0))[1] + prof.get("gemm_fp8", (0, 0.0, 0.0))[1]) / max(1, args.steps)
+    executed = gemm_exec + att_fwd * (1.0 if args.fwd_only else 3.0)
     line = {
         "metric": "img-text tokens/sec/GPU (ViT-L + Llama-7B, 6-frame interpair, seq4096)",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -564,13 +598,19 @@ def main(argv=None):
         "data": "synthetic", "tokens_per_s_per_gpu": round(value / world, 1),
         "config": {"workload": workload, "per_gpu_batch": B, "seq_len": S, "images_per_gpu": n_img, "parallelism": f"dp{world}",
                    "step": step_desc, "loss": round(loss_val, 4),
-                   # the same batch every step: a real optimizer step shows as a falling loss (first warm-up step -> last timed step)
-                   "loss_first_warmup_step": (round(float(loss_first), 4) if loss_first is not None else None)},
+                   # a real optimizer step shows as a falling loss (first warm-up step -> last timed step; with rotated batches of random token
+                   # ids only what generalises falls: the unigram / position statistics, not the memorised batch)
+                   "loss_first_warmup_step": (round(float(loss_first), 4) if loss_first is not None else None),
+                   "batches": ("1 (the same batch every step: --same-batch)" if (dry or len(dbatches) == 1) else
+                               f"{len(dbatches)} distinct seeded batches rotated through warm-up and the timed steps")},
         "useful_tflops_per_gpu": round(useful / (dt / args.steps) / 1e12, 1),
+        # what the kernels ran (GEMM launches as launched + attention), and the step-level fraction on THAT basis; `useful` = 3 x algorithmic forward
+        "executed_tflops_per_gpu": round(executed / (dt / args.steps) / 1e12, 1),
+        "mfma_roofline_frac_step_useful": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "peak_hbm_gb": round(peak_gb, 1),
         "hbm_headroom_gb": (None if dry else round(torch.cuda.get_device_properties(dev).total_memory / 1e9 - peak_gb, 1)),
         "mem_level": (None if dry else eng.mem_level),
-        "mfma_roofline_frac_step": round(useful / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "mfma_roofline_frac_step": round(executed / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": {"kernel": ("gemm_nt_256<F8> (scaled-fp8 MFMA GEMM, all launches)" if fp8_dom else "bf16 MFMA GEMM kernels (gemm_nt_256 / gemm_w4 / gemm_nt_128, all launches)"),
                      "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": traffic_unit, "launches": n,
@@ -598,6 +638,15 @@ def main(argv=None):
         # what RCCL was told (its own choice - ring / tree, LL / LL128 / simple - is per collective size unless pinned here)
         line["rccl_env"] = {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                         "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")}
+        line["rccl_choice"] = parse_rccl_tuning(locals().get("rccl_log"))
+        # SURVEY 8e's budget for the step's gradient bytes on 7 x ~153 GB/s xGMI links per GPU: a ring keeps ONE link per direction busy
+        # (2 (N-1)/N x bytes over one link), a direct reduce-scatter + all-gather spreads the same bytes over all N-1 peers' links
+        gb, N_ = line["comm_gb_per_step"], world
+        if N_ > 1:
+            line["comm_expected_ms"] = {"ring_one_link": round(2 * (N_ - 1) / N_ * gb / 153.0 * 1e3, 1),
+                                        "direct_all_links": round(2 * (N_ - 1) / N_ * gb / (153.0 * min(7, N_ - 1)) * 1e3, 1),
+                                        "measured_total": line["comm_ms_total"], "measured_exposed": line["comm_ms_exposed"],
+                                        "what": "per step; 14.09 GB at N = 8: 161 ms ring / 23 ms direct (SURVEY 8e)"}
         line["gemm_persistent"] = os.environ.get("MH_GEMM_PERSISTENT", "1") != "0"
         line["per_rank"] = [{"rank": i, "peak_hbm_gb": r[0], "comm_ms_total": r[1], "comm_ms_exposed": r[2]} for i, r in enumerate(per_rank)]
         line["recompute_fallback"] = recompute_fallback
@@ -666,6 +715,29 @@ def main(argv=None):
     os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dp:
         dist.destroy_process_group()
+
+
+def parse_rccl_tuning(path):
+    """{message bytes: "ALGO/PROTO"} from RCCL's NCCL_DEBUG_SUBSYS=TUNING lines ("AllReduce: 404750336 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}"); None when
+    no such line was written (one-rank groups short-cut before the tuner; NCCL_DEBUG set by the caller; a library that words it differently)."""
+    import re
+
+    if not path or not os.path.exists(path):
+        return None
+    algo = {"0": "TREE", "1": "RING", "2": "COLLNET_DIRECT", "3": "COLLNET_CHAIN", "4": "NVLS", "5": "NVLS_TREE", "6": "PAT"}  # (numeric in older builds;
+    proto = {"0": "LL", "1": "LL128", "2": "SIMPLE"}  # this image's librccl prints names: "%s: %ld Bytes -> Algo %s proto %s channel{Lo..Hi}={%d..%d}")
+    out = {}
+    try:
+        with open(path, errors="replace") as f:
+            for ln in f:
+                m = re.search(r"AllReduce: (\d+) Bytes -> Algo (\S+) proto (\S+)(?: channel\{Lo\.\.Hi\}=\{(\d+)\.\.(\d+)\})?", ln)
+                if m:
+                    ch = f" ch{m.group(4)}-{m.group(5)}" if m.group(4) is not None else ""
+                    out[int(m.group(1))] = f"{algo.get(m.group(2), m.group(2))}/{proto.get(m.group(3), m.group(3))}{ch}"
+        os.remove(path)
+    except Exception:
+        return None
+    return {str(k): v for k, v in sorted(out.items())} or None
 
 
 def cfg5_extra(model, eng, O, synth, to_dev, train_step, dev_sync, dev, warm=2, steps=4):

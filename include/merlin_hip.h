@@ -284,6 +284,10 @@ int mh_attn_bwd2_spill(const void* q, int64_t ldq, const void* k, int64_t ldk, c
 /* dK and dV at D = 128: 2 (default) = attn_bwd3_kv_k (one kernel; register-staged tile copies, three LDS stages, one barrier in the middle
  * of a tile), 1 = attn_bwd2_kv_k<MODE 3> (one kernel, LDS-DMA copies: rounds 2-4), 0 = two kernels.  A/B switch, bit-identical results. */
 void mh_attn_bwd_fused_kv(int on);
+/* The mode in force (0 / 1 / 2).  mh_attn_bwd2_spill takes its five-product form ONLY in mode 2 (the dS spill lives in attn_bwd3_kv_k); in modes
+ * 0 / 1 it runs exactly mh_attn_bwd2 and never touches ds_ws - callers that report which form ran ask here.  Env MH_ATTN_BWD_FUSED_KV sets the
+ * mode at import (since round 5 the value 1 selects the round 2-4 one-kernel form; before that it was the default and a no-op). */
+int mh_attn_bwd_fused_kv_mode(void);
 /* The row-per-lane epilogues of the attention kernels (o; dq, dk, dv) write 16 bytes per lane after a half-wave exchange (default, needs
  * 16-byte aligned rows: ld % 8 == 0) instead of 8 (0): A/B switch, bit-identical results (profiles/r05_attn_wide_stores.txt).
  * Limits of mh_attn_fwd2 / mh_attn_bwd2: one batch element's rows of q / k / v / dout must span < 2^31 bytes (S * ld * 2 < 2^31: the

@@ -1426,6 +1426,7 @@ int launch_bwd2(const Bwd2Args& a, hipStream_t st) {
 }  // namespace mhattn
 
 extern "C" void mh_attn_bwd_fused_kv(int on) { mhattn::g_attn_bwd_fused_kv = on < 0 ? 0 : (on > 2 ? 2 : on); }
+extern "C" int mh_attn_bwd_fused_kv_mode(void) { return mhattn::g_attn_bwd_fused_kv; }
 #ifdef MH_KV_TIMING
 static unsigned long long* g_kv_timing_dbg = nullptr;
 extern "C" void mh_kv_timing_buffer(void* p) { g_kv_timing_dbg = (unsigned long long*)p; }

@@ -1099,10 +1099,9 @@ class HipEngine:
                 sup = torch.zeros(B, S, dtype=torch.uint8, device=dev)
                 sup[:, :-1] = labels[:, 1:] != -100
                 rows_f, rows_i, cnt = O.mask_unpad_index(sup.view(1, T))
-                if getattr(self, "_sup_ring", None) is None:  # (pinned slots, one per forward in flight: a ring of 16)
-                    self._sup_ring, self._sup_slot = torch.empty(16, dtype=torch.int32, pin_memory=True), 0
-                slot = self._sup_ring[self._sup_slot % 16: self._sup_slot % 16 + 1]
-                self._sup_slot += 1
+                # one pinned word PER forward context (torch's caching host allocator recycles it when the context dies): any number of
+                # grad-enabled forwards may be outstanding before their backwards run (losses of many micro-batches summed, one .backward())
+                slot = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 slot.copy_(cnt, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()

@@ -863,20 +863,41 @@ def attn_bwd_spill(on: bool):
     ATTN_BWD_SPILL = bool(on)
 
 
+ATTN_SPILL_MAX_BYTES = int(float(os.environ.get("MH_ATTN_SPILL_MAX_GB", "12")) * 2 ** 30)  # cap of the dS scratch (cfg 5 needs 8.7 GB)
+
+
+def release_attn_scratch():
+    """Frees the persistent scratch of the attention backward (dS spill of the five-product form, delta / lse rows): call it when a
+    process goes from training to inference and wants the HBM back.  The next backward re-allocates what it needs."""
+    _spill_cache.clear()
+    _delta_cache.clear()
+
+
 def _spill_ws(B, S, H, device):
-    """dS scratch of the five-product attention backward (4.4 GB at cfg 3, 8.7 GB at cfg 5): ONE grow-only buffer per (device, stream), shared
-    by every layer (launches on one stream are ordered)."""
+    """dS scratch of the five-product attention backward (4.4 GB at cfg 3, 8.7 GB at cfg 5; O(B H S^2)): ONE grow-only buffer per
+    (device, stream), shared by every layer (launches on one stream are ordered).  Returns None - the caller then runs the
+    seven-product form, which needs no scratch - when the size exceeds ATTN_SPILL_MAX_BYTES (env MH_ATTN_SPILL_MAX_GB, default 12), exceeds a
+    quarter of the HBM that is free right now, cannot be allocated (OOM), or a graph capture is in progress.  `release_attn_scratch()` frees it."""
     lib = L.lib()
     lib.mh_attn_bwd_spill_bytes.restype = C.c_int64
     need = int(lib.mh_attn_bwd_spill_bytes(i32(B), i32(S), i32(H)))
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _spill_cache.get(key)
     if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing() or need > ATTN_SPILL_MAX_BYTES:
+            return None
+        have = 0 if ws is None else ws.numel()
+        free_b = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        if need - have > free_b // 4:
             return None
         if len(_spill_cache) > 4:
             _spill_cache.clear()
-        ws = _spill_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        _spill_cache.pop(key, None)
+        del ws
+        try:
+            ws = _spill_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        except torch.cuda.OutOfMemoryError:
+            return None
     return ws
 
 
@@ -889,7 +910,9 @@ def attn_bwd2(q, k, v, o, do, lse, B, S, H, D, causal, seqlens=None, dq=None, dk
     dv = torch.empty(B * S, H * D, dtype=q.dtype, device=q.device) if dv is None else dv
     delta = _delta_ws(B, H, round_up(S, 64), q.device)  # [delta | lse*log2e]
     use_spill = ATTN_BWD_SPILL if spill is None else spill
-    ws = _spill_ws(B, S, H, q.device) if (use_spill and causal and D == 128 and S % 128 == 0 and seqlens is None) else None
+    # (the dS spill lives in attn_bwd3_kv_k = fused-kv mode 2; in modes 0 / 1 the library would run the seven-product kernels and ignore ds_ws)
+    use_spill = use_spill and causal and D == 128 and S % 128 == 0 and seqlens is None and int(L.lib().mh_attn_bwd_fused_kv_mode()) == 2
+    ws = _spill_ws(B, S, H, q.device) if use_spill else None
     global LAST_ATTN_BWD_FORM
     if causal and D == 128:
         LAST_ATTN_BWD_FORM = "five-product" if ws is not None else "seven-product"  # (tests: which form the last causal D = 128 call took)

@@ -45,6 +45,18 @@ def test_bench_self_launches_two_workers_and_prints_one_line():
     _check(_json_lines(p.stdout), 2)
 
 
+def test_bench_self_launches_eight_workers_the_scale_run_shape():
+    """The driver's SCALE run ends at N = 8 (one rank per GPU of the node): the launcher, the rendezvous, GradSync's fixed collective order, the
+    per-rank gathers and the ONE line, with eight gloo workers on this host."""
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check(_json_lines(p.stdout), 8)
+
+
 def test_bench_under_the_drivers_torchrun_command_line():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

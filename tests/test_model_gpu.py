@@ -270,6 +270,47 @@ def test_lm_head_backward_over_the_scored_rows_only(dtype):
         assert cos >= 0.9999, (k, cos)
 
 
+def test_scored_rows_count_survives_many_outstanding_forwards():
+    """the scored-row count of a grad-enabled forward is read back in ITS backward.  Twenty forwards with DIFFERENT scored-row counts
+    are left outstanding (their losses summed, one .backward()): every backward must use its own count - the gradients equal those of the dense
+    head on the same twenty micro-batches.  (A shared ring of 16 slots silently dropped scored rows of forwards 0-3 here.)"""
+    from merlin_amd import synth
+    from oracle import cases as C
+
+    cfg = C.tiny_cfg()
+    model = _build(cfg, torch.bfloat16)
+    batches = []
+    for i in range(20):
+        b = synth.interpair_batch(B=4, S=512, frames=12, base_vocab=cfg.vocab_size - 3, P=cfg.num_patches, image_size=cfg.v_image_size, rank=i)
+        lab = b["labels"].clone()
+        lab[:, : 512 - 20 - 11 * i] = -100  # 4 x (19 + 11 i) scored positions: another count (and another 256-row bucket) per forward
+        b["labels"] = lab
+        batches.append(_to_dev(b))
+    counts = [int((b["labels"][:, 1:] != -100).sum()) for b in batches]
+    assert len(set(counts)) == 20 and len({(c + 255) // 256 for c in counts}) >= 4 and 2 * ((max(counts) + 255) // 256 * 256) <= 2048, counts
+    grads = {}
+    for sparse in (False, True):
+        for p in model.parameters():
+            p.grad = None
+        model.engine.sparse_head = model.engine.sparse_last_layer = sparse
+        total = None
+        for b in batches:
+            loss = model(**b).loss
+            total = loss if total is None else total + loss
+        total.backward()
+        grads[sparse] = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    model.engine.sparse_head = model.engine.sparse_last_layer = True
+    bad = []
+    for k, g in grads[False].items():
+        a = grads[True][k]
+        if float(g.abs().max()) == 0.0:
+            continue
+        cos = float((a.reshape(-1).double() @ g.reshape(-1).double()) / (a.double().norm() * g.double().norm()))
+        if cos < 0.9999 or abs(float(a.double().norm() / g.double().norm()) - 1) > 5e-3:
+            bad.append((k, cos, float(a.double().norm() / g.double().norm())))
+    assert not bad, bad[:6]
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name", ["tiny_2img", "tiny_padbatch"])
 def test_mem_level_rederived_activations_give_the_same_gradients(name, dtype):

@@ -142,13 +142,15 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
   }
 }
 
-int g_gemm_gm = 4;     // raster group height (tile rows); measured 4 < 8 < 16 on the decoder shapes (profiles/r02_gemm_raster_ab.txt)
+int g_gemm_gm = 0;     // raster group height (tile rows); 0 = automatic: 4 (measured 4 < 8 < 16 on the decoder shapes, profiles/r02_gemm_raster_ab.txt), or ALL tile rows when
+                       // there are at most 8 of them (a short prefill: a group of 4 leaves the 5th 128-row tile row of a 613-token sequence in a group of its own, whose
+                       // tiles re-read every weight panel on other XCDs; cfg-2 forward 14.59 -> 14.38 ms same box, profiles/r06_cfg2_raster_ab.txt)
 int g_force_kernel = 0;  // 0 auto, 128, 256 (8 waves), 4 (4 waves), 5.. (timing probes) - tests / A-B benchmarking
 
 }  // namespace
 
 extern "C" void mh_gemm_force_kernel(int which) { g_force_kernel = which; }
-extern "C" void mh_gemm_raster_group(int gm) { g_gemm_gm = gm >= 1 && gm <= 64 ? gm : 4; }
+extern "C" void mh_gemm_raster_group(int gm) { g_gemm_gm = gm >= 1 && gm <= 64 ? gm : 0; }
 
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* bias, const void* resid, int64_t ldr, int M, int N, int K, int dt,
@@ -500,7 +502,7 @@ extern "C" int mh_wgrad_grouped(const MhWgradProblem* pr, int n, int T, int dt, 
     if (!w4_can_run(g, 1, 1)) return MH_ERR_SHAPE;
     gs[i] = g;
   }
-  return launch_gemm_w4_grouped(gs, n, dt, g_gemm_gm, as_stream(stream));
+  return launch_gemm_w4_grouped(gs, n, dt, g_gemm_gm ? g_gemm_gm : 4, as_stream(stream));
 }
 
 extern "C" int mh_gemm_splitk_max(int M, int N, int K) {

@@ -31,7 +31,7 @@ struct GemmArgs {
   const int* sc_e_flag;  // device word, non-zero when any exponent of the image is non-zero (written by the quantiser); may be null
   int sc_e_group;
   int sw_mode, sw_ff;
-  int gm;  // raster: tiles are visited in groups of gm tile-rows x all tile-columns (tile_of)
+  int gm;  // raster: tiles are visited in groups of gm tile-rows x all tile-columns (tile_of); 0 = automatic (4, or every tile row when there are <= 8)
   void* sw_out;
   const void* sw_in;
   int64_t sw_ldo, sw_ldi;
@@ -48,7 +48,7 @@ constexpr int BK = 64;
 __device__ __forceinline__ void tile_of(const GemmArgs& g, int v, int nwg, int& tm, int& tn) {
   const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int GM = g.gm;  // tile rows per raster group (launcher: g_gemm_gm)
+  const int GM = g.gm > 0 ? g.gm : (g.tiles_m <= 8 ? g.tiles_m : 4);  // tile rows per raster group (launcher: g_gemm_gm; 0 = automatic)
   const int per_group = GM * g.tiles_n;
   const int group = tile / per_group;
   const int first_m = group * GM;

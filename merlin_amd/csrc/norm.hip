@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const uint16_t* __restric
   }
 }
 
-// fp32-RESIDUAL-STREAM forms (engine.fp32_residual; DESIGN.md "fp32 residual stream"): the stream x is fp32 [rows, d] and is
+// fp32-RESIDUAL-STREAM forms (engine.fp32_residual; HISTORY.md §4 "fp32 residual streams"): the stream x is fp32 [rows, d] and is
 // updated in place by the o / down (out_proj / fc2) projections' accumulating fp32 epilogue, so the only 16-bit roundings left on
 // the forward path are the GEMM operands.  This kernel is the stream's reader: y = norm(x) in 16 bits for the next GEMM, and
 // (x16 != NULL) the 16-bit copy of x that the backward keeps as the layer input.  Same arithmetic and summation order as

@@ -445,7 +445,7 @@ def test_fp8_training_step_at_cfg5_real_length_S8192_vs_oracle():
     rng = float(logits_ref.abs().max())
     mx, rms = float(d.abs().max()) / rng, float(d.pow(2).mean().sqrt()) / rng
     print(f"[fp8 train cfg 5 S=8192] logits max {mx:.3e} rms {rms:.3e} loss {float(out.loss):.5f} oracle {float(loss_ref):.5f}")
-    # the fp8 step's stated tolerances (e4m3 operands).  The rms is stable (0.0270 with either kernel family); the single-element maximum over 8192 x 32003
+    # the fp8 step's stated tolerances (e4m3 operands, HISTORY §7).  The rms is stable (0.0270 with either kernel family); the single-element maximum over 8192 x 32003
     # logits scatters with summation order (0.196 with the 8-wave fused forms, 0.203 with the 4-wave ones): bound 0.22
     assert mx < 0.22 and rms < 0.04, (mx, rms)
     assert abs(float(out.loss) - float(loss_ref)) < 2e-2 * float(loss_ref)

@@ -3,7 +3,7 @@
 // STATUS: A/B arm (mh_gemm_force_kernel(4)), not dispatched by default - measured on the cfg-3 shapes it ties the
 // 8-wave kernel on the big plain GEMMs (1.39-1.45 PFLOP/s) and loses where the epilogue reads a residual/bias or K is
 // short (half as many waves share the same epilogue work); kept with its timing probes (VAR) as the record of what
-// was learnt about one-wave-per-SIMD scheduling on gfx950 (GEMM section).
+// was learnt about one-wave-per-SIMD scheduling on gfx950 (HISTORY.md §3, GEMM rows).
 //
 // Why a second 256-tile kernel: with 8 waves (gemm256.hip) every wave owns 128x64 outputs, so a K-step of 32
 // costs 12 fragment reads per 32 MFMAs and the block needs 8 barriers per K-tile.  Here a wave owns 128x128

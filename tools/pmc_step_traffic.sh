@@ -3,7 +3,7 @@
 # separate rocprofv3 --pmc passes (no tracing combined with --pmc) over `bench.py --steps 1 --warmup 1`.
 # Run on the GPU box from the repo root: bash tools/pmc_step_traffic.sh   (writes gpurun_out/$OUT)
 # PMC_CONFIG=cfg5 bash tools/pmc_step_traffic.sh r05_gemm_traffic_cfg5.json: the same for the fp8 step of cfg 5 (bench.py quotes it in extras.cfg5).
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=${1:-r05_gemm_traffic.json}; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=${1:-r06_gemm_traffic.json}; cd /tmp && export TMPDIR=/tmp
 CFGARGS=""; [ "${PMC_CONFIG:-cfg3}" = "cfg5" ] && CFGARGS="--config cfg5"
 mkdir -p $R/gpurun_out
 i=0

@@ -1,4 +1,4 @@
-// What a tile-copy instruction costs a wave that is otherwise issuing MFMAs back to back (profiles/r05_vmem_issue_probe.txt).
+// What a tile-copy instruction costs a wave that is otherwise issuing MFMAs back to back (profiles/r05_vmem_issue_probe.txt; HISTORY §5 / §7 (0)).
 // Every wave loops over {PER independent 16x16x32 MFMAs (inline asm, AccVGPR accumulators); one vector-memory instruction of form MODE}; one block per CU
 // (140 KiB of LDS), 256 threads = one wave per SIMD (WAVES = 4) or 512 = two per SIMD (WAVES = 8).  The data is L2-resident (each CU walks its own window: 64 KiB = L2-resident footprint, 1 MiB = Infinity Cache / HBM).
 // hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/vmem_issue_probe.hip -o tools/probes/vmem_issue_probe.so ; python tools/probes/vmem_issue_probe.py

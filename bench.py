@@ -32,6 +32,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC only on these hosts: without it RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument`.  Exported on the GPU boxes already; set here as
+# well (before the HIP runtime comes up) so that a bare torchrun environment cannot lose it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
